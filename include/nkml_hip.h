@@ -1,0 +1,148 @@
+/*
+ * nkml_hip.h - C ABI of the MI355X (gfx950) k-mer coverage-normalisation hot path.
+ *
+ * The reference program (normalise_kmers_multi_large.c, "ref" below) has no FFI or plugin
+ * interface: its hot path is the file-local call
+ *     bool process_sequence_pair(fwd_seq, rev_seq, hash_table, &fwd_high, &fwd_total,
+ *                                &rev_high, &rev_total, thread_id, K, depth_per_cpu)   ref:279-280, 1551-1566
+ *     bool process_sequence_single(fwd_seq, hash_table, &high, &total, ...)              ref:1539-1550
+ * made once per record from process_thread_chunk_paired (ref:1629) / _single (ref:1976), on a table that
+ * lives for the whole run (ref:2279).  A per-record call is useless for a GPU, so this ABI is the same
+ * contract in batch form: a context owns the k-mer table for the run; each call takes a batch of reads
+ * in stream order and returns, per read, the two integers the reference's callers consume
+ * (high-count k-mers, total k-mers).  The float32 keep/skip test (ref:1641-1646, 1988-1992) is exported
+ * separately so the host record loop can stay where it is.
+ *
+ * Semantics (equal to the reference whenever its table is collision-free, i.e. capacity == 4^k, ref:676-684):
+ *   count[x] starts at 0; k-mer occurrences are taken in stream order (read order, window left to right);
+ *   each occurrence does count[x] += 1 and is "high" iff count[x] >= depth afterwards (ref:1486-1497);
+ *   windows whose 2-bit code is 0 are neither counted nor totalled (ref:1483-1484);
+ *   'N' is read as 'A' (ref:1406); reads shorter than k must not be submitted (the caller drops the
+ *   record like ref:1630-1631); any byte outside ACGTN is an error (the reference exits, ref:1416-1420).
+ *   Results do not depend on how the stream is cut into batches.
+ *
+ * Plain C types only.  All functions return NKML_OK (0) or a negative NKML_E_* code; none calls exit().
+ * A context may be used from one host thread at a time.
+ */
+#ifndef NKML_HIP_H
+#define NKML_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NKML_ABI_VERSION 1
+
+enum {
+    NKML_OK = 0,
+    NKML_E_ARG = -1,        /* bad argument (k outside 5..31 ref:724, depth < 2 ref:734, null pointer, batch too large) */
+    NKML_E_HIP = -2,        /* a HIP runtime call failed; see nkml_last_error() */
+    NKML_E_NOMEM = -3,      /* device or host allocation failed (reference: exit on calloc failure, ref:1071-1075) */
+    NKML_E_BADBASE = -4,    /* a sequence byte outside ACGTN (reference: FATAL + exit, ref:1416-1420, 1445-1454) */
+    NKML_E_STATE = -5,      /* call order violated (collect without submit, ...) */
+    NKML_E_NODEVICE = -6    /* no usable gfx950 device */
+};
+
+typedef struct nkml_ctx nkml_ctx;
+
+typedef struct nkml_config {
+    int32_t ksize;            /* --ksize, 5..31 (ref:535, 724) */
+    int32_t depth;            /* --depth; the threshold compared is depth / cpus with cpus == 1 (ref:674) */
+    int32_t canonical;        /* --canonical (ref:1472) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t memory_gb;        /* --memory_start: initial capacity of the hashed table used for k > 16, in GiB of
+                                 16-byte slots like ref:416-422; 0 = the reference default of 1 GiB (ref:137).
+                                 k <= 16 uses a direct-addressed counter array of 4^k entries (what ref:678-684
+                                 clamps to) and ignores this field. */
+    uint32_t max_batch_reads; /* largest n_reads of one batch */
+    uint64_t max_batch_bases; /* largest total sequence bytes of one batch (< 2^32) */
+    uint32_t chunk_bases;     /* window positions counted per internal pass; 0 = default (32 Mi) */
+    uint32_t flags;           /* NKML_F_* */
+} nkml_config;
+
+#define NKML_F_PROFILE 1u     /* time the counting kernel with HIP events on the context's stream */
+
+typedef struct nkml_stats {
+    uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */
+    uint64_t capacity;         /* table slots (4^k for the direct table) */
+    uint64_t table_bytes;
+    uint64_t kmers_counted;    /* occurrences that went through the table since create/reset (sum of all 'total') */
+    uint64_t kmers_saturated;  /* of those, occurrences answered from the saturation bitmap without an atomic */
+    uint64_t crossing_kmers;   /* k-mers whose count reached depth so far */
+    uint64_t crossing_occurrences; /* occurrences that needed exact stream-order ranking */
+    uint64_t resizes;          /* hashed table growth events (expand_local_hash_table, ref:1055-1108) */
+    double count_kernel_ms;    /* NKML_F_PROFILE: summed duration of the counting kernel's launches */
+    uint64_t count_kernel_launches;
+    uint64_t count_kernel_keys;    /* window positions those launches covered */
+} nkml_stats;
+
+/* Library/ABI probes (no GPU needed). */
+int nkml_abi_version(void);
+const char *nkml_strerror(int code);
+/* Message of the last failure on this context (static buffer owned by the context). */
+const char *nkml_last_error(const nkml_ctx *ctx);
+
+/* Life cycle.  Replaces init_hash_table / destroy_hash_table (ref:881-906) and the per-run table of ref:2279.
+ * Fails with NKML_E_NODEVICE when no gfx950 device is present: there is no CPU fallback. */
+int nkml_create(const nkml_config *cfg, nkml_ctx **out);
+void nkml_destroy(nkml_ctx *ctx);
+/* Forget every count (a fresh run on the same context). */
+int nkml_reset(nkml_ctx *ctx);
+/* Use a caller-owned HIP stream (hipStream_t passed as void*) instead of the context's own. */
+int nkml_set_stream(nkml_ctx *ctx, void *hip_stream);
+int nkml_synchronize(nkml_ctx *ctx);
+int nkml_get_stats(nkml_ctx *ctx, nkml_stats *out);
+
+/* Host-buffer path (what the command-line host uses): reads concatenated in `seq`, read i occupies
+ * [offsets[i], offsets[i+1]); mates of a pair are consecutive reads (forward first, ref:1559-1563).
+ * submit stages the batch with hipMemcpyAsync and enqueues the kernels; collect waits and returns the
+ * per-read counters in submission order.  Batch form of process_sequence_pair/_single (ref:1551, 1539). */
+int nkml_submit(nkml_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
+int nkml_collect(nkml_ctx *ctx, int32_t *high, int32_t *total);
+
+/* Device-buffer path: the same batch already resident in HBM; d_high/d_total are device arrays of n_reads.
+ * Asynchronous on the context's stream. */
+int nkml_process_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads,
+                        uint64_t n_bases, int32_t *d_high, int32_t *d_total);
+
+/* Seeding insert, batch form of sequence_to_hash_zero (ref:1501-1537): keys enter the table with count 0.
+ * Only nkml_stats.unique_kmers can tell the difference.  Host buffers, synchronous. */
+int nkml_seed(nkml_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
+
+/* Keep/skip test, float32 with strict '<' (ref:1641-1646 paired; ref:1988-1992 single). Host side. */
+int nkml_keep_pair(int32_t fwd_high, int32_t fwd_total, int32_t rev_high, int32_t rev_total, float coverage);
+int nkml_keep_single(int32_t high, int32_t total, float coverage);
+/* The same test for a whole batch on the device: reads 2i and 2i+1 are the mates of pair i (paired != 0),
+ * or every read on its own (paired == 0).  d_keep gets one byte per pair / read. */
+int nkml_decide_device(nkml_ctx *ctx, const int32_t *d_high, const int32_t *d_total, uint32_t n_units,
+                       int paired, float coverage, uint8_t *d_keep);
+
+/* Stages of nkml_process_device, exported for the k-mer-sharded multi-GPU path, where the keys are exchanged
+ * between devices (all-to-all) after the first stage and the flags travel back before the last one.
+ *   kmerise : sequence bytes -> one key per base position (0 where no countable window starts); key width is
+ *             4 bytes for k <= 16, else 8 (nkml_key_bytes).  Restates ref:1464-1484 + encode/canonical.
+ *   count   : keys in stream order -> one flag byte per key (NKML_FLAG_*), updating the table.  Restates
+ *             store_kmer + the high test (ref:929-1053, 1486-1497) with exact stream-order ranks.
+ *   reduce  : per read, high = number of NKML_FLAG_HIGH flags, total = number of non-zero keys. */
+int nkml_key_bytes(const nkml_ctx *ctx);
+int nkml_kmerise_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads,
+                        uint64_t n_bases, void *d_keys);
+int nkml_count_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint8_t *d_flags);
+int nkml_reduce_reads_device(nkml_ctx *ctx, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets,
+                             uint32_t n_reads, int32_t *d_high, int32_t *d_total);
+
+#define NKML_FLAG_NONE 0u /* no k-mer at this position */
+#define NKML_FLAG_HIGH 1u /* occurrence whose stream-order count is >= depth */
+#define NKML_FLAG_LOW 2u  /* counted, below depth */
+
+/* Table dump for --print (print_kmer_table, ref:354-385): up to max_entries (code, count) pairs of every
+ * stored k-mer, unsorted like the reference; *n_entries gets the number available. Host arrays, synchronous. */
+int nkml_dump_table(nkml_ctx *ctx, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NKML_HIP_H */

@@ -1,0 +1,1196 @@
+// HIP kernels (gfx950 / MI355X) of the k-mer coverage-normalisation hot path and the C ABI around them.
+//
+// Data layout in HBM for one batch of n_bases sequence bytes (reads concatenated, stream order):
+//   seq       u8  [n_bases]            ASCII as read from FASTQ/FASTA
+//   packed    u32 [ceil(n_bases/16)+4] 2-bit codes, 16 bases per word, first base in the top bits
+//   startbits u32 [same]               bit j of word w set  <=>  base 16w+j is the first base of a read
+//                                      (plus one sentinel bit at n_bases)
+//   keys      u32|u64 [16*words]       per base position: code of the k-mer starting there, 0 = none
+//   flags     u8  [16*words]           per base position: NKML_FLAG_*
+// The table lives for the whole run:
+//   k <= 16 : counts u32[4^k] (direct-addressed, what the reference degenerates to when capacity == 4^k,
+//             normalise_kmers_multi_large.c:676-684), sat/cross bitmaps of 4^k bits each
+//   k >  16 : 16-byte slots {key u64, count u32, state u32}, open addressing with linear probing
+//             (same slot size as kmer_t, normalise_kmers_multi_large.c:156-161)
+//
+// Order: the reference is sequential, and an occurrence is "high" iff its 1-based stream-order rank among
+// the occurrences of its k-mer is >= depth (normalise_kmers_multi_large.c:1486-1497).  Atomic adds give
+// arbitrary ranks inside one parallel pass, so the pass is split:
+//   (1) k-mers whose count was already >= depth-1 when the pass began ("saturated", one bit per k-mer, frozen
+//       during the pass) are high whatever the order, and need no update at all;
+//   (2) every other occurrence does one atomic add; a k-mer can only be mis-ranked if its count reaches depth
+//       inside this pass ("crossing"); the occurrence that sees the count become depth flags the k-mer;
+//   (3) occurrences of crossing k-mers (a small set: each k-mer crosses once per run) are collected, sorted by
+//       (k-mer, position) and given their true ranks: with m occurrences in the pass and final count F, the
+//       i-th in stream order (0-based) has rank F - m + i + 1.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "nkml_hip.h"
+
+namespace {
+
+constexpr uint32_t FLAG_NONE = NKML_FLAG_NONE, FLAG_HIGH = NKML_FLAG_HIGH, FLAG_LOW = NKML_FLAG_LOW;
+constexpr uint32_t SEEDED_BIT = 0x80000000u; // direct table: k-mer present through seeding (count part may be 0)
+constexpr uint32_t COUNT_MASK = 0x7fffffffu;
+constexpr uint32_t ST_SAT = 1u, ST_CROSS = 2u, ST_SEEDED = 4u; // hashed table slot state bits
+
+struct alignas(256) Counters {
+    unsigned long long unique;    // distinct k-mers stored (hash_table->used)
+    unsigned long long counted;   // occurrences with a non-zero key
+    unsigned long long saturated; // of those, answered by the saturation bit
+    unsigned int n_sat_new;       // S list length (count reached depth-1 in this pass)
+    unsigned int n_cross;         // X list length (count reached depth in this pass)
+    unsigned int n_occ;           // E list length (occurrences of crossing k-mers)
+    unsigned int bad_bases;       // bytes outside ACGTN seen by the packer
+    unsigned int probe_overflow;  // hashed table: a probe sequence wrapped (table full) - must stay 0
+};
+
+struct Slot {
+    unsigned long long key; // 0 = empty
+    unsigned int count;
+    unsigned int state;
+};
+static_assert(sizeof(Slot) == 16, "slot layout");
+
+// ------------------------------------------------------------------------------------------------------
+// K0: read starts -> startbits.  One bit per base position; a window is valid iff no read starts inside it
+// after its first base.  The sentinel at n_bases ends the last read.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_mark_starts(const uint64_t *__restrict__ offsets, uint32_t n_reads,
+                                                     uint32_t *__restrict__ startbits)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > n_reads) return;
+    uint64_t p = offsets[i];
+    atomicOr(&startbits[p >> 4], 1u << (p & 15));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1: ASCII -> 2-bit, 16 bases per 32-bit word, first base in the top bits (the order of encode_kmer_plain,
+// normalise_kmers_multi_large.c:1118-1126; codes of base_map :150-153; N reads as A like replacestr :1406).
+// Each lane turns one 16-byte load into one 4-byte store; both sides are fully coalesced, so nothing is
+// staged through LDS.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack4(uint32_t v, uint32_t &bad)
+{
+    // A=0x41 C=0x43 G=0x47 T=0x54 N=0x4e : ((c>>1)^(c>>2))&3 -> 0,1,2,3,0
+    uint32_t x = ((v >> 1) ^ (v >> 2)) & 0x03030303u;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        uint32_t c = (v >> (8 * b)) & 0xffu;
+        bad += !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N');
+    }
+    return (x * 0x40100401u) >> 24; // byte 0 (first base) lands in the top two bits of the result byte
+}
+
+__global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, uint64_t n_bases,
+                                              uint32_t *__restrict__ packed, uint64_t n_words, Counters *ctr)
+{
+    uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t bad = 0;
+    if (w < n_words) {
+        uint64_t base = w * 16;
+        uint32_t v[4];
+        if (base + 16 <= n_bases && ((reinterpret_cast<uintptr_t>(seq) & 15) == 0)) {
+            uint4 q = *reinterpret_cast<const uint4 *>(seq + base);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint64_t p = base + 4 * i + b;
+                    uint32_t c = (p < n_bases) ? seq[p] : (uint32_t)'A';
+                    x |= c << (8 * b);
+                }
+                v[i] = x;
+            }
+        }
+        uint32_t word = (pack4(v[0], bad) << 24) | (pack4(v[1], bad) << 16) | (pack4(v[2], bad) << 8) | pack4(v[3], bad);
+        packed[w] = word;
+    }
+    if (bad) atomicAdd(&ctr->bad_bases, bad);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2: one lane per packed word = 16 window starts.  The lane needs the next one or two words as well; they
+// come from the neighbouring lanes with wavefront shuffles (the last two lanes of a wave load theirs).
+// Forward code and reverse-complement code roll from window to window; canonical = the smaller
+// (get_canonical_kmer, normalise_kmers_multi_large.c:1175-1180).  Writes 0 where no window of a single read
+// starts, or where the code is 0 (skipped by the reference, :1483-1484).
+// ------------------------------------------------------------------------------------------------------
+template <typename KEY, bool CANON>
+__global__ void __launch_bounds__(256) k_kmerise(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
+                                                 uint64_t n_bases, uint64_t n_words, int k, KEY *__restrict__ keys)
+{
+    uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    bool live = w < n_words;
+    uint32_t w0 = live ? packed[w] : 0u;         // packed/startbits carry 4 zero words of halo
+    uint32_t s0 = live ? startbits[w] : 0u;
+    uint32_t w1 = __shfl_down(w0, 1), w2 = __shfl_down(w0, 2);
+    uint32_t s1 = __shfl_down(s0, 1), s2 = __shfl_down(s0, 2);
+    if (live && lane >= 62) {
+        if (lane == 63) { w1 = packed[w + 1]; s1 = startbits[w + 1]; }
+        w2 = packed[w + 2]; s2 = startbits[w + 2];
+    }
+    if (!live) return;
+
+    const uint64_t S = (uint64_t)s0 | ((uint64_t)s1 << 16) | ((uint64_t)s2 << 32);
+    const uint64_t span = (1ull << (k - 1)) - 1;             // positions 1..k-1 after the window start
+    const uint64_t hi = ((uint64_t)w0 << 32) | w1;           // bases 0..31 of this lane's 48
+    const uint64_t mask = (1ull << (2 * k)) - 1;             // k <= 31
+    // first window: bases 0..k-1 (k <= 31 < 32, so they all sit in hi)
+    uint64_t fwd = hi >> (64 - 2 * k), rc = 0;
+    if (CANON) {
+        // reverse complement of fwd: reverse the 2-bit groups, complement
+        uint64_t x = ~fwd & mask;
+        uint64_t r = 0;
+        for (int i = 0; i < k; i++) { r = (r << 2) | (x & 3ull); x >>= 2; }
+        rc = r;
+    }
+    const uint64_t rem = n_bases - w * 16; // bases from this word's first position to the end of the batch
+    KEY out[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j > 0) {
+            int p = j + k - 1; // incoming base position, 1..46
+            uint64_t b = (p < 32) ? ((hi >> (62 - 2 * p)) & 3ull) : (((uint64_t)w2 >> (94 - 2 * p)) & 3ull);
+            fwd = ((fwd << 2) | b) & mask;
+            if (CANON) rc = (rc >> 2) | ((3ull - b) << (2 * (k - 1)));
+        }
+        bool valid = ((S >> (j + 1)) & span) == 0 && (uint64_t)(j + k) <= rem;
+        uint64_t code = fwd;
+        if (CANON) code = rc < fwd ? rc : fwd;
+        out[j] = valid ? (KEY)code : (KEY)0;
+    }
+    KEY *dst = keys + w * 16;
+    if (sizeof(KEY) == 4) {
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+        for (int q = 0; q < 4; q++) d4[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    } else {
+        ulonglong2 *d2 = reinterpret_cast<ulonglong2 *>(dst);
+#pragma unroll
+        for (int q = 0; q < 8; q++) d2[q] = make_ulonglong2(out[2 * q], out[2 * q + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Block-level sum of three per-thread tallies, then one atomic each (a per-occurrence atomic on one word
+// would serialise the whole chip).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void flush_tallies(uint32_t uniq, uint32_t counted, uint32_t sat, Counters *ctr)
+{
+    __shared__ uint32_t red[3][4];
+    uniq = wave_sum(uniq); counted = wave_sum(counted); sat = wave_sum(sat);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = uniq; red[1][wv] = counted; red[2][wv] = sat; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        uint32_t b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        uint32_t c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (a) atomicAdd(&ctr->unique, (unsigned long long)a);
+        if (b) atomicAdd(&ctr->counted, (unsigned long long)b);
+        if (c) atomicAdd(&ctr->saturated, (unsigned long long)c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3 (k <= 16): count one chunk of keys against the direct-addressed table.  Restates store_kmer's insert /
+// increment (normalise_kmers_multi_large.c:948-1008) and the high test (:1494-1497).  Four keys per lane: the
+// four bitmap gathers, then the four atomic adds, are independent and in flight together.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_count_direct(const uint32_t *__restrict__ keys, uint64_t n4, uint8_t *__restrict__ flags,
+                                                      uint32_t *__restrict__ counts, const uint32_t *__restrict__ sat,
+                                                      uint32_t *__restrict__ cross, uint32_t depth, int count_saturated,
+                                                      Counters *ctr, uint32_t *__restrict__ list_sat,
+                                                      uint32_t *__restrict__ list_cross)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t uniq = 0, counted = 0, nsat = 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+        uint4 kv = reinterpret_cast<const uint4 *>(keys)[q];
+        uint32_t key[4] = {kv.x, kv.y, kv.z, kv.w};
+        uint32_t sw[4], old[4], fl[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sw[u] = key[u] ? sat[key[u] >> 5] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool is_sat = (sw[u] >> (key[u] & 31)) & 1u;
+            old[u] = 0;
+            fl[u] = FLAG_NONE;
+            if (key[u]) {
+                counted++;
+                if (is_sat) {
+                    fl[u] = FLAG_HIGH;
+                    nsat++;
+                    if (count_saturated) atomicAdd(&counts[key[u]], 1u);
+                } else {
+                    fl[u] = FLAG_LOW;
+                    old[u] = atomicAdd(&counts[key[u]], 1u);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (fl[u] == FLAG_LOW) {
+                uint32_t c1 = (old[u] & COUNT_MASK) + 1;
+                if (old[u] == 0) uniq++;
+                if (c1 == depth - 1) list_sat[atomicAdd(&ctr->n_sat_new, 1u)] = key[u];
+                if (c1 == depth) {
+                    list_cross[atomicAdd(&ctr->n_cross, 1u)] = key[u];
+                    atomicOr(&cross[key[u] >> 5], 1u << (key[u] & 31));
+                }
+            }
+        }
+        reinterpret_cast<uint32_t *>(flags)[q] = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
+    }
+    flush_tallies(uniq, counted, nsat, ctr);
+}
+
+// Seeding (sequence_to_hash_zero, normalise_kmers_multi_large.c:1501-1537): the key becomes present, its count
+// is left alone.
+__global__ void __launch_bounds__(256) k_seed_direct(const uint32_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ counts,
+                                                     Counters *ctr)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t uniq = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        uint32_t key = keys[i];
+        if (key && atomicOr(&counts[key], SEEDED_BIT) == 0) uniq++;
+    }
+    flush_tallies(uniq, 0, 0, ctr);
+}
+
+// K4a: collect the occurrences of crossing k-mers of this chunk: (id << posbits) | position-in-chunk.
+template <typename KEY>
+__device__ __forceinline__ void append_occurrence(bool pred, uint64_t value, unsigned long long *__restrict__ occ, Counters *ctr)
+{
+    unsigned long long m = __ballot(pred);
+    if (m == 0) return;
+    int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&ctr->n_occ, (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    if (pred) occ[base + __popcll(m & ((1ull << lane) - 1))] = value;
+}
+
+__global__ void __launch_bounds__(256) k_collect_direct(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ flags,
+                                                        uint64_t n4, const uint32_t *__restrict__ cross, int posbits,
+                                                        unsigned long long *__restrict__ occ, Counters *ctr)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t n4r = (n4 + stride - 1) / stride * stride; // every lane runs the same trip count (ballots inside)
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < n4r; q += stride) {
+        uint32_t f4 = 0;
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (q < n4) {
+            f4 = reinterpret_cast<const uint32_t *>(flags)[q];
+            if (f4 & 0x02020202u) kv = reinterpret_cast<const uint4 *>(keys)[q];
+        }
+        uint32_t key[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool low = ((f4 >> (8 * u)) & 0xffu) == FLAG_LOW;
+            bool hit = low && ((cross[key[u] >> 5] >> (key[u] & 31)) & 1u);
+            append_occurrence<uint32_t>(hit, ((uint64_t)key[u] << posbits) | (q * 4 + u), occ, ctr);
+        }
+    }
+}
+
+// K4b: exact stream-order ranks for the sorted occurrences.  occ is sorted by (id, position); an id's group is
+// found by two binary searches; the i-th member (0-based) of a group of m whose k-mer ended the pass at count F
+// has rank F - m + i + 1.
+template <typename TABLE>
+__global__ void __launch_bounds__(256) k_rank(const unsigned long long *__restrict__ occ, uint32_t n_occ, int posbits,
+                                              TABLE table, uint32_t depth, uint8_t *__restrict__ flags)
+{
+    uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_occ) return;
+    unsigned long long e = occ[s];
+    unsigned long long id = e >> posbits;
+    unsigned long long lo_key = id << posbits, hi_key = (id + 1) << posbits;
+    uint32_t lo = 0, hi = s; // first index with occ >= lo_key, in [0, s]
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (occ[mid] < lo_key) lo = mid + 1; else hi = mid; }
+    uint32_t start = lo;
+    lo = s + 1; hi = n_occ;  // first index with occ >= hi_key, in (s, n_occ]
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (occ[mid] < hi_key) lo = mid + 1; else hi = mid; }
+    uint32_t m = lo - start, i = s - start;
+    uint32_t F = table.count_of(id);
+    if (F - m + i + 1 >= depth) flags[e & ((1ull << posbits) - 1)] = (uint8_t)FLAG_HIGH;
+}
+
+struct DirectTable {
+    const uint32_t *counts;
+    __device__ uint32_t count_of(unsigned long long id) const { return counts[id] & COUNT_MASK; }
+};
+struct HashedTable {
+    const Slot *slots;
+    __device__ uint32_t count_of(unsigned long long id) const { return slots[id].count; }
+};
+
+// K4c: between passes, k-mers that reached depth-1 become saturated; crossing marks are cleared.
+__global__ void __launch_bounds__(256) k_apply_direct(const uint32_t *__restrict__ list_sat, uint32_t n_sat,
+                                                      const uint32_t *__restrict__ list_cross, uint32_t n_cross,
+                                                      uint32_t *__restrict__ sat, uint32_t *__restrict__ cross)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_sat) { uint32_t k = list_sat[i]; atomicOr(&sat[k >> 5], 1u << (k & 31)); }
+    if (i < n_cross) {
+        uint32_t k = list_cross[i];
+        atomicOr(&sat[k >> 5], 1u << (k & 31));
+        atomicAnd(&cross[k >> 5], ~(1u << (k & 31)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3 (k > 16): hashed table.  One lane per key, linear probing from a mixed hash; the key is claimed with a
+// 64-bit compare-and-swap (store_kmer's insert, normalise_kmers_multi_large.c:948-971), the count bumped with
+// an atomic add (:1003).  A plain load may show a stale "empty" - the CAS then reports the true owner - but a
+// non-zero key never changes, so a matching or foreign key read by a plain load can be trusted.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+// returns the slot index of key (inserting it if absent), or ~0 if the probe wrapped; *inserted tells a new key
+__device__ __forceinline__ uint64_t find_or_insert(Slot *__restrict__ slots, uint64_t cap_mask, uint64_t key, bool &inserted,
+                                                   uint32_t &state)
+{
+    uint64_t h = mix64(key) & cap_mask;
+    inserted = false;
+    for (uint64_t probes = 0; probes <= cap_mask; probes++) {
+        uint4 raw = *reinterpret_cast<const uint4 *>(&slots[h]);
+        unsigned long long cur = ((unsigned long long)raw.y << 32) | raw.x;
+        state = raw.w;
+        if (cur == 0) {
+            cur = atomicCAS(&slots[h].key, 0ull, (unsigned long long)key);
+            if (cur == 0) { inserted = true; state = 0; return h; }
+            if (cur == key) { state = 0; return h; } // inserted by another lane during this pass: not saturated yet
+        }
+        if (cur == key) return h;
+        h = (h + 1) & cap_mask;
+    }
+    return ~0ull;
+}
+
+__global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *__restrict__ keys, uint64_t n, uint8_t *__restrict__ flags,
+                                                      unsigned long long *__restrict__ slot_of, Slot *__restrict__ slots,
+                                                      uint64_t cap_mask, uint32_t depth, int count_saturated, Counters *ctr,
+                                                      unsigned long long *__restrict__ list_sat,
+                                                      unsigned long long *__restrict__ list_cross)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t uniq = 0, counted = 0, nsat = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned long long key = keys[i];
+        uint32_t fl = FLAG_NONE;
+        if (key) {
+            counted++;
+            bool inserted; uint32_t state;
+            uint64_t h = find_or_insert(slots, cap_mask, key, inserted, state);
+            if (h == ~0ull) { atomicAdd(&ctr->probe_overflow, 1u); }
+            else {
+                if (inserted) uniq++;
+                if (state & ST_SAT) {
+                    fl = FLAG_HIGH;
+                    nsat++;
+                    if (count_saturated) atomicAdd(&slots[h].count, 1u);
+                } else {
+                    fl = FLAG_LOW;
+                    slot_of[i] = h;
+                    uint32_t c1 = atomicAdd(&slots[h].count, 1u) + 1;
+                    if (c1 == depth - 1) list_sat[atomicAdd(&ctr->n_sat_new, 1u)] = h;
+                    if (c1 == depth) {
+                        list_cross[atomicAdd(&ctr->n_cross, 1u)] = h;
+                        atomicOr(&slots[h].state, ST_CROSS);
+                    }
+                }
+            }
+        }
+        flags[i] = (uint8_t)fl;
+    }
+    flush_tallies(uniq, counted, nsat, ctr);
+}
+
+__global__ void __launch_bounds__(256) k_seed_hashed(const unsigned long long *__restrict__ keys, uint64_t n, Slot *__restrict__ slots,
+                                                     uint64_t cap_mask, Counters *ctr)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t uniq = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        unsigned long long key = keys[i];
+        if (!key) continue;
+        bool inserted; uint32_t state;
+        uint64_t h = find_or_insert(slots, cap_mask, key, inserted, state);
+        if (h == ~0ull) atomicAdd(&ctr->probe_overflow, 1u);
+        else if (inserted) uniq++;
+    }
+    flush_tallies(uniq, 0, 0, ctr);
+}
+
+__global__ void __launch_bounds__(256) k_collect_hashed(const uint8_t *__restrict__ flags, const unsigned long long *__restrict__ slot_of,
+                                                        uint64_t n, const Slot *__restrict__ slots, int posbits,
+                                                        unsigned long long *__restrict__ occ, Counters *ctr)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t nr = (n + stride - 1) / stride * stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nr; i += stride) {
+        bool hit = false;
+        unsigned long long h = 0;
+        if (i < n && flags[i] == FLAG_LOW) {
+            h = slot_of[i];
+            hit = (slots[h].state & ST_CROSS) != 0;
+        }
+        append_occurrence<unsigned long long>(hit, (h << posbits) | i, occ, ctr);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_apply_hashed(const unsigned long long *__restrict__ list_sat, uint32_t n_sat,
+                                                      const unsigned long long *__restrict__ list_cross, uint32_t n_cross,
+                                                      Slot *__restrict__ slots)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_sat) atomicOr(&slots[list_sat[i]].state, ST_SAT);
+    if (i < n_cross) {
+        atomicOr(&slots[list_cross[i]].state, ST_SAT);
+        atomicAnd(&slots[list_cross[i]].state, ~ST_CROSS);
+    }
+}
+
+// Growth (expand_local_hash_table, normalise_kmers_multi_large.c:1055-1108): every stored key moves to a table
+// twice the size.  Keys are distinct, so after the CAS has claimed a slot its other fields are written plainly.
+__global__ void __launch_bounds__(256) k_rehash(const Slot *__restrict__ old_slots, uint64_t old_cap, Slot *__restrict__ new_slots,
+                                                uint64_t new_mask, Counters *ctr)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < old_cap; i += stride) {
+        Slot s = old_slots[i];
+        if (!s.key) continue;
+        uint64_t h = mix64(s.key) & new_mask;
+        uint64_t probes = 0;
+        for (; probes <= new_mask; probes++) {
+            if (atomicCAS(&new_slots[h].key, 0ull, s.key) == 0ull) {
+                new_slots[h].count = s.count;
+                new_slots[h].state = s.state;
+                break;
+            }
+            h = (h + 1) & new_mask;
+        }
+        if (probes > new_mask) atomicAdd(&ctr->probe_overflow, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K5: per read, high = flags equal to HIGH, total = non-zero keys (sequence_to_hash's two counters,
+// normalise_kmers_multi_large.c:1486, 1496).  One wavefront per read, 64 positions per step.
+// ------------------------------------------------------------------------------------------------------
+template <typename KEY>
+__global__ void __launch_bounds__(256) k_reduce_reads(const KEY *__restrict__ keys, const uint8_t *__restrict__ flags,
+                                                      const uint64_t *__restrict__ offsets, uint32_t n_reads,
+                                                      int32_t *__restrict__ high, int32_t *__restrict__ total)
+{
+    uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_reads) return;
+    int lane = threadIdx.x & 63;
+    uint64_t a = offsets[r], b = offsets[r + 1];
+    uint32_t h = 0, t = 0;
+    for (uint64_t p = a + lane; p < b; p += 64) {
+        h += flags[p] == FLAG_HIGH;
+        t += keys[p] != 0;
+    }
+    h = wave_sum(h);
+    t = wave_sum(t);
+    if (lane == 0) { high[r] = (int32_t)h; total[r] = (int32_t)t; }
+}
+
+// Keep/skip, float32, strict '<' (normalise_kmers_multi_large.c:1641-1646, 1988-1992).  __fdiv_rn is the IEEE
+// round-to-nearest divide the host's (float)high / total performs.
+__device__ __forceinline__ float ratio_f32(int32_t high, int32_t total)
+{
+    return total > 0 ? __fdiv_rn((float)high, (float)total) : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) k_decide(const int32_t *__restrict__ high, const int32_t *__restrict__ total, uint32_t n_units,
+                                                int paired, float coverage, uint8_t *__restrict__ keep)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_units) return;
+    if (paired) {
+        float rf = ratio_f32(high[2 * i], total[2 * i]), rr = ratio_f32(high[2 * i + 1], total[2 * i + 1]);
+        keep[i] = (rf < coverage && rr < coverage) ? 1 : 0;
+    } else {
+        keep[i] = ratio_f32(high[i], total[i]) < coverage ? 1 : 0;
+    }
+}
+
+// table dump helpers
+__global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, uint64_t cap, unsigned long long *codes,
+                                                     uint32_t *cnts, uint64_t max_entries, unsigned long long *n_out)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += stride) {
+        uint32_t v = counts[i];
+        if (v) {
+            unsigned long long at = atomicAdd(n_out, 1ull);
+            if (at < max_entries) { codes[at] = i; cnts[at] = v & COUNT_MASK; }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_dump_hashed(const Slot *__restrict__ slots, uint64_t cap, unsigned long long *codes,
+                                                     uint32_t *cnts, uint64_t max_entries, unsigned long long *n_out)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += stride) {
+        Slot s = slots[i];
+        if (s.key) {
+            unsigned long long at = atomicAdd(n_out, 1ull);
+            if (at < max_entries) { codes[at] = s.key; cnts[at] = s.count; }
+        }
+    }
+}
+
+} // namespace
+
+// ======================================================================================================
+// Host side: context and C ABI
+// ======================================================================================================
+struct nkml_ctx {
+    nkml_config cfg;
+    int key_bytes;          // 4 for k <= 16, else 8
+    bool direct;
+    hipStream_t stream;
+    bool own_stream;
+    char err[512];
+
+    // table
+    uint32_t *counts;       // direct
+    uint32_t *sat, *cross;  // direct bitmaps
+    Slot *slots;            // hashed
+    uint64_t capacity;      // slots / counters
+    uint64_t resizes;
+
+    // per-batch buffers
+    uint64_t max_words;     // ceil(max_batch_bases / 16)
+    uint8_t *d_seq;
+    uint64_t *d_offsets;
+    uint32_t *d_packed, *d_startbits;
+    void *d_keys;
+    uint8_t *d_flags;
+    unsigned long long *d_slot_of; // hashed: slot index of each LOW occurrence
+    int32_t *d_high, *d_total;
+
+    // per-chunk buffers
+    uint32_t chunk;         // keys per counting pass
+    int posbits;
+    void *d_list_sat, *d_list_cross;
+    unsigned long long *d_occ, *d_occ_sorted;
+    void *d_sort_tmp;
+    size_t sort_tmp_bytes;
+
+    Counters *d_ctr;
+    Counters *h_ctr;        // pinned
+    // pinned staging for the host path
+    uint8_t *h_seq;
+    uint64_t *h_offsets;
+    int32_t *h_high, *h_total;
+    uint32_t pending_reads; // reads of the submitted, not yet collected batch
+    bool pending;
+
+    // stats
+    uint64_t crossing_kmers, crossing_occ;
+    hipEvent_t ev0, ev1;
+    double count_ms;
+    uint64_t count_launches, count_keys;
+};
+
+namespace {
+
+int fail(nkml_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? NKML_E_NOMEM : NKML_E_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+    } while (0)
+
+inline uint32_t blocks_for(uint64_t n, uint32_t per_block = 256) { return (uint32_t)((n + per_block - 1) / per_block); }
+constexpr uint32_t GRID_PERSIST = 256 * 8; // 8 workgroups of 256 lanes per CU, grid-stride beyond
+
+uint64_t default_hashed_capacity(int memory_gb)
+{
+    // the reference sizes its table in 16-byte slots (normalise_kmers_multi_large.c:411-422); default 1 GiB (:137).
+    uint64_t gb = memory_gb > 0 ? (uint64_t)memory_gb : 1;
+    uint64_t slots = gb << 26; // GiB / 16 B
+    uint64_t cap = 1;
+    while (cap < slots) cap <<= 1;
+    return cap;
+}
+
+int alloc_table(nkml_ctx *c)
+{
+    if (c->direct) {
+        c->capacity = 1ull << (2 * c->cfg.ksize);
+        HIPCHK(c, hipMalloc(&c->counts, c->capacity * sizeof(uint32_t)));
+        uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
+        HIPCHK(c, hipMalloc(&c->sat, bm));
+        HIPCHK(c, hipMalloc(&c->cross, bm));
+    } else {
+        c->capacity = default_hashed_capacity(c->cfg.memory_gb);
+        HIPCHK(c, hipMalloc(&c->slots, c->capacity * sizeof(Slot)));
+    }
+    return NKML_OK;
+}
+
+int clear_table(nkml_ctx *c)
+{
+    if (c->direct) {
+        uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
+        HIPCHK(c, hipMemsetAsync(c->counts, 0, c->capacity * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->sat, 0, bm, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->cross, 0, bm, c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->slots, 0, c->capacity * sizeof(Slot), c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+    c->crossing_kmers = c->crossing_occ = 0;
+    c->count_ms = 0;
+    c->count_launches = c->count_keys = 0;
+    return NKML_OK;
+}
+
+int fetch_counters(nkml_ctx *c)
+{
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NKML_OK;
+}
+
+// Grow the hashed table until `incoming` more distinct keys still leave it under 80 % full
+// (TABLE_LOAD_FACTOR, normalise_kmers_multi_large.c:143, 933).
+int ensure_capacity(nkml_ctx *c, uint64_t incoming)
+{
+    if (c->direct) return NKML_OK;
+    uint64_t used = c->h_ctr->unique;
+    while ((double)(used + incoming) >= (double)c->capacity * 0.8) {
+        uint64_t ncap = c->capacity * 2;
+        Slot *ns = nullptr;
+        HIPCHK(c, hipMalloc(&ns, ncap * sizeof(Slot)));
+        HIPCHK(c, hipMemsetAsync(ns, 0, ncap * sizeof(Slot), c->stream));
+        hipLaunchKernelGGL(k_rehash, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, ns, ncap - 1, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->slots));
+        c->slots = ns;
+        c->capacity = ncap;
+        c->resizes++;
+    }
+    return NKML_OK;
+}
+
+// K0-K2 on the context's stream.
+int run_kmerise(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, void *d_keys)
+{
+    uint64_t n_words = (n_bases + 15) / 16;
+    HIPCHK(c, hipMemsetAsync(c->d_startbits, 0, (n_words + 4) * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_packed + n_words, 0, 4 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_mark_starts, blocks_for((uint64_t)n_reads + 1), 256, 0, c->stream, d_offsets, n_reads, c->d_startbits);
+    hipLaunchKernelGGL(k_pack, blocks_for(n_words), 256, 0, c->stream, d_seq, n_bases, c->d_packed, n_words, c->d_ctr);
+    const int k = c->cfg.ksize;
+    const uint32_t g = blocks_for(n_words);
+    if (c->key_bytes == 4) {
+        if (c->cfg.canonical)
+            hipLaunchKernelGGL((k_kmerise<uint32_t, true>), g, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, (uint32_t *)d_keys);
+        else
+            hipLaunchKernelGGL((k_kmerise<uint32_t, false>), g, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, (uint32_t *)d_keys);
+    } else {
+        if (c->cfg.canonical)
+            hipLaunchKernelGGL((k_kmerise<unsigned long long, true>), g, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, (unsigned long long *)d_keys);
+        else
+            hipLaunchKernelGGL((k_kmerise<unsigned long long, false>), g, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, (unsigned long long *)d_keys);
+    }
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+// K3 + K4 over keys [0, n) in chunks; n is a multiple of 16.
+int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, bool seeding)
+{
+    const uint32_t depth = (uint32_t)c->cfg.depth;
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0;
+    for (uint64_t a = 0; a < n; a += c->chunk) {
+        uint64_t len = n - a < c->chunk ? n - a : c->chunk;
+        int rc;
+        if (!c->direct) {
+            if ((rc = ensure_capacity(c, len)) != NKML_OK) return rc;
+        }
+        if (seeding) {
+            if (c->direct)
+                hipLaunchKernelGGL(k_seed_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len, c->counts, c->d_ctr);
+            else
+                hipLaunchKernelGGL(k_seed_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, c->slots,
+                                   c->capacity - 1, c->d_ctr);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = fetch_counters(c)) != NKML_OK) return rc;
+            continue;
+        }
+        if (profile) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        if (c->direct) {
+            hipLaunchKernelGGL(k_count_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len / 4, d_flags + a, c->counts,
+                               c->sat, c->cross, depth, 0, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
+        } else {
+            hipLaunchKernelGGL(k_count_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, d_flags + a,
+                               c->d_slot_of, c->slots, c->capacity - 1, depth, 0, c->d_ctr, (unsigned long long *)c->d_list_sat,
+                               (unsigned long long *)c->d_list_cross);
+        }
+        HIPCHK(c, hipGetLastError());
+        if (profile) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        if ((rc = fetch_counters(c)) != NKML_OK) return rc;
+        if (profile) {
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            c->count_ms += ms;
+            c->count_launches++;
+            c->count_keys += len;
+        }
+        if (c->h_ctr->probe_overflow) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
+        uint32_t n_sat = c->h_ctr->n_sat_new, n_cross = c->h_ctr->n_cross;
+        if (n_cross) {
+            if (c->direct)
+                hipLaunchKernelGGL(k_collect_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, d_flags + a, len / 4, c->cross,
+                                   c->posbits, c->d_occ, c->d_ctr);
+            else
+                hipLaunchKernelGGL(k_collect_hashed, GRID_PERSIST, 256, 0, c->stream, d_flags + a, c->d_slot_of, len, c->slots, c->posbits,
+                                   c->d_occ, c->d_ctr);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = fetch_counters(c)) != NKML_OK) return rc;
+            uint32_t n_occ = c->h_ctr->n_occ;
+            if (n_occ) {
+                int idbits = 0;
+                while (idbits < 64 && (c->capacity - 1) >> idbits) idbits++;
+                size_t tmp = c->sort_tmp_bytes;
+                HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, tmp, c->d_occ, c->d_occ_sorted, (size_t)n_occ, 0u,
+                                                   (unsigned)(c->posbits + idbits), c->stream));
+                if (c->direct)
+                    hipLaunchKernelGGL((k_rank<DirectTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
+                                       DirectTable{c->counts}, depth, d_flags + a);
+                else
+                    hipLaunchKernelGGL((k_rank<HashedTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
+                                       HashedTable{c->slots}, depth, d_flags + a);
+                HIPCHK(c, hipGetLastError());
+            }
+            c->crossing_kmers += n_cross;
+            c->crossing_occ += n_occ;
+        }
+        if (n_sat || n_cross) {
+            uint32_t m = n_sat > n_cross ? n_sat : n_cross;
+            if (c->direct)
+                hipLaunchKernelGGL(k_apply_direct, blocks_for(m), 256, 0, c->stream, (const uint32_t *)c->d_list_sat, n_sat,
+                                   (const uint32_t *)c->d_list_cross, n_cross, c->sat, c->cross);
+            else
+                hipLaunchKernelGGL(k_apply_hashed, blocks_for(m), 256, 0, c->stream, (const unsigned long long *)c->d_list_sat, n_sat,
+                                   (const unsigned long long *)c->d_list_cross, n_cross, c->slots);
+            HIPCHK(c, hipGetLastError());
+            // the three list lengths restart at zero for the next pass
+            HIPCHK(c, hipMemsetAsync(&c->d_ctr->n_sat_new, 0, 3 * sizeof(unsigned int), c->stream));
+        }
+    }
+    return NKML_OK;
+}
+
+int run_reduce(nkml_ctx *c, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high,
+               int32_t *d_total)
+{
+    if (n_reads == 0) return NKML_OK;
+    if (c->key_bytes == 4)
+        hipLaunchKernelGGL((k_reduce_reads<uint32_t>), blocks_for(n_reads, 4), 256, 0, c->stream, (const uint32_t *)d_keys, d_flags, d_offsets,
+                           n_reads, d_high, d_total);
+    else
+        hipLaunchKernelGGL((k_reduce_reads<unsigned long long>), blocks_for(n_reads, 4), 256, 0, c->stream, (const unsigned long long *)d_keys,
+                           d_flags, d_offsets, n_reads, d_high, d_total);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int check_batch(nkml_ctx *c, uint32_t n_reads, uint64_t n_bases)
+{
+    if (n_reads > c->cfg.max_batch_reads) return fail(c, NKML_E_ARG, "batch of %u reads exceeds max_batch_reads %u", n_reads, c->cfg.max_batch_reads);
+    if (n_bases > c->cfg.max_batch_bases) return fail(c, NKML_E_ARG, "batch of %llu bases exceeds max_batch_bases %llu", (unsigned long long)n_bases, (unsigned long long)c->cfg.max_batch_bases);
+    return NKML_OK;
+}
+
+int check_bad_bases(nkml_ctx *c)
+{
+    if (c->h_ctr->bad_bases) {
+        unsigned int n = c->h_ctr->bad_bases;
+        hipMemsetAsync(&c->d_ctr->bad_bases, 0, sizeof(unsigned int), c->stream);
+        return fail(c, NKML_E_BADBASE, "%u sequence byte(s) outside ACGTN", n);
+    }
+    return NKML_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int nkml_abi_version(void) { return NKML_ABI_VERSION; }
+
+const char *nkml_strerror(int code)
+{
+    switch (code) {
+    case NKML_OK: return "ok";
+    case NKML_E_ARG: return "invalid argument";
+    case NKML_E_HIP: return "HIP runtime error";
+    case NKML_E_NOMEM: return "out of memory";
+    case NKML_E_BADBASE: return "sequence byte outside ACGTN";
+    case NKML_E_STATE: return "invalid call order or internal state";
+    case NKML_E_NODEVICE: return "no gfx950 device";
+    default: return "unknown error";
+    }
+}
+
+const char *nkml_last_error(const nkml_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int nkml_create(const nkml_config *cfg, nkml_ctx **out)
+{
+    if (!cfg || !out) return NKML_E_ARG;
+    *out = nullptr;
+    if (cfg->ksize < 5 || cfg->ksize > 31) return NKML_E_ARG; // normalise_kmers_multi_large.c:724
+    if (cfg->depth < 2) return NKML_E_ARG;                    // :734
+    if (cfg->max_batch_bases == 0 || cfg->max_batch_bases >= (1ull << 32) || cfg->max_batch_reads == 0) return NKML_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return NKML_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return NKML_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return NKML_E_NODEVICE;
+    if (hipSetDevice(cfg->device) != hipSuccess) return NKML_E_NODEVICE;
+
+    nkml_ctx *c = new (std::nothrow) nkml_ctx();
+    if (!c) return NKML_E_NOMEM;
+    memset(c, 0, sizeof *c);
+    c->cfg = *cfg;
+    c->direct = cfg->ksize <= 16;
+    c->key_bytes = c->direct ? 4 : 8;
+    uint32_t chunk = cfg->chunk_bases ? cfg->chunk_bases : (32u << 20);
+    chunk = (chunk + 63) & ~63u;
+    if (chunk > (1u << 30)) chunk = 1u << 30;
+    c->chunk = chunk;
+    c->posbits = 0;
+    while ((1ull << c->posbits) < chunk) c->posbits++;
+    c->max_words = (cfg->max_batch_bases + 15) / 16;
+    const uint64_t npos = c->max_words * 16;
+
+#define CREATE_CHK(call)                                                   \
+    do {                                                                   \
+        int rc_ = (call);                                                  \
+        if (rc_ != NKML_OK) { *out = c; return rc_; }                      \
+    } while (0)
+#define CREATE_HIP(call)                                                                                         \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            int rc_ = fail(c, e_ == hipErrorOutOfMemory ? NKML_E_NOMEM : NKML_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            *out = c;                                                                                            \
+            return rc_;                                                                                          \
+        }                                                                                                        \
+    } while (0)
+
+    CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    CREATE_HIP(hipEventCreate(&c->ev0));
+    CREATE_HIP(hipEventCreate(&c->ev1));
+    CREATE_HIP(hipMalloc(&c->d_ctr, sizeof(Counters)));
+    CREATE_HIP(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
+    memset(c->h_ctr, 0, sizeof(Counters));
+    CREATE_CHK(alloc_table(c));
+    CREATE_HIP(hipMalloc(&c->d_seq, npos + 64));
+    CREATE_HIP(hipMalloc(&c->d_offsets, ((uint64_t)cfg->max_batch_reads + 1) * sizeof(uint64_t)));
+    CREATE_HIP(hipMalloc(&c->d_packed, (c->max_words + 4) * sizeof(uint32_t)));
+    CREATE_HIP(hipMalloc(&c->d_startbits, (c->max_words + 4) * sizeof(uint32_t)));
+    CREATE_HIP(hipMalloc(&c->d_keys, npos * c->key_bytes));
+    CREATE_HIP(hipMalloc(&c->d_flags, npos));
+    if (!c->direct) CREATE_HIP(hipMalloc(&c->d_slot_of, (uint64_t)c->chunk * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&c->d_high, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
+    CREATE_HIP(hipMalloc(&c->d_total, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
+    const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
+    CREATE_HIP(hipMalloc(&c->d_list_sat, per_chunk * c->key_bytes));
+    CREATE_HIP(hipMalloc(&c->d_list_cross, per_chunk * c->key_bytes));
+    CREATE_HIP(hipMalloc(&c->d_occ, per_chunk * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&c->d_occ_sorted, per_chunk * sizeof(unsigned long long)));
+    {
+        size_t tmp = 0;
+        CREATE_HIP(rocprim::radix_sort_keys(nullptr, tmp, c->d_occ, c->d_occ_sorted, (size_t)per_chunk, 0u, 64u, c->stream));
+        c->sort_tmp_bytes = tmp ? tmp : 256;
+        CREATE_HIP(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes));
+    }
+    CREATE_HIP(hipHostMalloc(&c->h_seq, npos + 64, hipHostMallocDefault));
+    CREATE_HIP(hipHostMalloc(&c->h_offsets, ((uint64_t)cfg->max_batch_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    CREATE_HIP(hipHostMalloc(&c->h_high, (uint64_t)cfg->max_batch_reads * sizeof(int32_t), hipHostMallocDefault));
+    CREATE_HIP(hipHostMalloc(&c->h_total, (uint64_t)cfg->max_batch_reads * sizeof(int32_t), hipHostMallocDefault));
+    CREATE_CHK(clear_table(c));
+    CREATE_HIP(hipStreamSynchronize(c->stream));
+#undef CREATE_CHK
+#undef CREATE_HIP
+    *out = c;
+    return NKML_OK;
+}
+
+void nkml_destroy(nkml_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->counts); hipFree(c->sat); hipFree(c->cross); hipFree(c->slots);
+    hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
+    hipFree(c->d_keys); hipFree(c->d_flags); hipFree(c->d_slot_of); hipFree(c->d_high); hipFree(c->d_total);
+    hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
+    hipFree(c->d_ctr);
+    if (c->h_ctr) hipHostFree(c->h_ctr);
+    if (c->h_seq) hipHostFree(c->h_seq);
+    if (c->h_offsets) hipHostFree(c->h_offsets);
+    if (c->h_high) hipHostFree(c->h_high);
+    if (c->h_total) hipHostFree(c->h_total);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int nkml_reset(nkml_ctx *c)
+{
+    if (!c) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = clear_table(c);
+    if (rc != NKML_OK) return rc;
+    memset(c->h_ctr, 0, sizeof(Counters));
+    c->pending = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NKML_OK;
+}
+
+int nkml_set_stream(nkml_ctx *c, void *hip_stream)
+{
+    if (!c) return NKML_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) HIPCHK(c, hipStreamDestroy(c->stream));
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return NKML_OK;
+}
+
+int nkml_synchronize(nkml_ctx *c)
+{
+    if (!c) return NKML_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NKML_OK;
+}
+
+int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
+{
+    if (!c || !out) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = fetch_counters(c);
+    if (rc != NKML_OK) return rc;
+    memset(out, 0, sizeof *out);
+    out->unique_kmers = c->h_ctr->unique;
+    out->capacity = c->capacity;
+    out->table_bytes = c->direct ? c->capacity * 4 + 2 * (c->capacity / 8) : c->capacity * sizeof(Slot);
+    out->kmers_counted = c->h_ctr->counted;
+    out->kmers_saturated = c->h_ctr->saturated;
+    out->crossing_kmers = c->crossing_kmers;
+    out->crossing_occurrences = c->crossing_occ;
+    out->resizes = c->resizes;
+    out->count_kernel_ms = c->count_ms;
+    out->count_kernel_launches = c->count_launches;
+    out->count_kernel_keys = c->count_keys;
+    return NKML_OK;
+}
+
+int nkml_key_bytes(const nkml_ctx *c) { return c ? c->key_bytes : NKML_E_ARG; }
+
+int nkml_kmerise_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, void *d_keys)
+{
+    if (!c || !d_seq || !d_offsets || !d_keys) return NKML_E_ARG;
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return run_kmerise(c, d_seq, d_offsets, n_reads, n_bases, d_keys);
+}
+
+int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint8_t *d_flags)
+{
+    if (!c || !d_keys || !d_flags || (n_keys & 15)) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return run_count(c, d_keys, n_keys, d_flags, false);
+}
+
+int nkml_reduce_reads_device(nkml_ctx *c, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads,
+                             int32_t *d_high, int32_t *d_total)
+{
+    if (!c || !d_keys || !d_flags || !d_offsets || !d_high || !d_total) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return run_reduce(c, d_keys, d_flags, d_offsets, n_reads, d_high, d_total);
+}
+
+int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
+                        int32_t *d_high, int32_t *d_total)
+{
+    if (!c || !d_seq || !d_offsets || !d_high || !d_total) return NKML_E_ARG;
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    if (n_reads == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if ((rc = run_kmerise(c, d_seq, d_offsets, n_reads, n_bases, c->d_keys)) != NKML_OK) return rc;
+    uint64_t n_keys = (n_bases + 15) / 16 * 16;
+    if ((rc = run_count(c, c->d_keys, n_keys, c->d_flags, false)) != NKML_OK) return rc;
+    if ((rc = check_bad_bases(c)) != NKML_OK) return rc;
+    return run_reduce(c, c->d_keys, c->d_flags, d_offsets, n_reads, d_high, d_total);
+}
+
+static int stage_host_batch(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads, uint64_t *n_bases_out)
+{
+    if (!c || !seq || !offsets) return NKML_E_ARG;
+    if (offsets[0] != 0) return fail(c, NKML_E_ARG, "offsets[0] must be 0");
+    uint64_t n_bases = offsets[n_reads];
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    const int k = c->cfg.ksize;
+    for (uint32_t i = 0; i < n_reads; i++) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] < (uint64_t)k)
+            return fail(c, NKML_E_ARG, "read %u is shorter than k=%d (the caller drops such records)", i, k);
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    memcpy(c->h_seq, seq, n_bases);
+    memcpy(c->h_offsets, offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t));
+    HIPCHK(c, hipMemcpyAsync(c->d_seq, c->h_seq, n_bases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_offsets, c->h_offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    *n_bases_out = n_bases;
+    return NKML_OK;
+}
+
+int nkml_submit(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads)
+{
+    if (!c) return NKML_E_ARG;
+    if (c->pending) return fail(c, NKML_E_STATE, "previous batch not collected");
+    if (n_reads == 0) { c->pending = true; c->pending_reads = 0; return NKML_OK; }
+    uint64_t n_bases = 0;
+    int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
+    if (rc != NKML_OK) return rc;
+    if ((rc = nkml_process_device(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->d_high, c->d_total)) != NKML_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_high, c->d_high, (uint64_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, (uint64_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    c->pending = true;
+    c->pending_reads = n_reads;
+    return NKML_OK;
+}
+
+int nkml_collect(nkml_ctx *c, int32_t *high, int32_t *total)
+{
+    if (!c || !high || !total) return NKML_E_ARG;
+    if (!c->pending) return fail(c, NKML_E_STATE, "nothing submitted");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(high, c->h_high, (uint64_t)c->pending_reads * sizeof(int32_t));
+    memcpy(total, c->h_total, (uint64_t)c->pending_reads * sizeof(int32_t));
+    c->pending = false;
+    return NKML_OK;
+}
+
+int nkml_seed(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads)
+{
+    if (!c) return NKML_E_ARG;
+    if (n_reads == 0) return NKML_OK;
+    uint64_t n_bases = 0;
+    int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
+    if (rc != NKML_OK) return rc;
+    if ((rc = run_kmerise(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->d_keys)) != NKML_OK) return rc;
+    if ((rc = run_count(c, c->d_keys, (n_bases + 15) / 16 * 16, c->d_flags, true)) != NKML_OK) return rc;
+    return check_bad_bases(c);
+}
+
+static inline float host_ratio(int32_t high, int32_t total)
+{
+    volatile float r = total > 0 ? (float)high / (float)total : 0.0f;
+    return r;
+}
+
+int nkml_keep_pair(int32_t fwd_high, int32_t fwd_total, int32_t rev_high, int32_t rev_total, float coverage)
+{
+    return host_ratio(fwd_high, fwd_total) < coverage && host_ratio(rev_high, rev_total) < coverage;
+}
+
+int nkml_keep_single(int32_t high, int32_t total, float coverage) { return host_ratio(high, total) < coverage; }
+
+int nkml_decide_device(nkml_ctx *c, const int32_t *d_high, const int32_t *d_total, uint32_t n_units, int paired, float coverage,
+                       uint8_t *d_keep)
+{
+    if (!c || !d_high || !d_total || !d_keep) return NKML_E_ARG;
+    if (n_units == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(k_decide, blocks_for(n_units), 256, 0, c->stream, d_high, d_total, n_units, paired, coverage, d_keep);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries)
+{
+    if (!c || !n_entries || (max_entries && (!codes || !counts))) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    unsigned long long *d_codes = nullptr, *d_n = nullptr;
+    uint32_t *d_cnts = nullptr;
+    uint64_t room = max_entries ? max_entries : 1;
+    HIPCHK(c, hipMalloc(&d_codes, room * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&d_cnts, room * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&d_n, sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
+    if (c->direct)
+        hipLaunchKernelGGL(k_dump_direct, GRID_PERSIST, 256, 0, c->stream, c->counts, c->capacity, d_codes, d_cnts, max_entries, d_n);
+    else
+        hipLaunchKernelGGL(k_dump_hashed, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, d_codes, d_cnts, max_entries, d_n);
+    HIPCHK(c, hipGetLastError());
+    unsigned long long n = 0;
+    HIPCHK(c, hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t take = n < max_entries ? n : max_entries;
+    if (take) {
+        HIPCHK(c, hipMemcpy(codes, d_codes, take * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(counts, d_cnts, take * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    *n_entries = n;
+    hipFree(d_codes); hipFree(d_cnts); hipFree(d_n);
+    return NKML_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,218 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the vectors captured from the
+compiled reference.  Integer work: every comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from tests.helpers import (Oracle, drive_oracle, golden_arrays, golden_meta, input_path, parse_args, records)
+
+pytestmark = pytest.mark.gpu
+
+META = golden_meta()
+FIELDS = ("high_fwd", "high_rev", "total_fwd", "total_rev")
+
+
+@pytest.fixture(scope="module")
+def nk():
+    import nomalise_kmers_multi_large_amd as m
+    return m
+
+
+def drive_gpu(nk, cfg, seed=True, **kw):
+    """The reference's main() loop (seeding pass, then every file pair / single file in order on one table,
+    normalise_kmers_multi_large.c:2242-2250, 2310-2393) with the HIP path doing the per-read work."""
+    k, cov = cfg["k"], np.float32(cfg["cov"])
+    fwd = [records(input_path(p), cfg["fastq_in"]) for p in cfg["fwd"]]
+    rev = [records(input_path(p), cfg["fastq_in"]) for p in cfg["rev"]]
+    out = dict(kept=[], high_fwd=[], high_rev=[], total_fwd=[], total_rev=[], per_file=[])
+    with nk.KmerNormaliser(k, cfg["depth"], cfg["cov"], cfg["canonical"], **kw) as g:
+        if seed:
+            n_seed = 1 + int(3e6 / len(fwd))
+            for i in range(len(fwd)):
+                for recs in ([fwd[i]] + ([rev[i]] if i < len(rev) else [])):
+                    reads = [r[1] for r in recs if len(r[1]) > k][:n_seed]
+                    if reads:
+                        g.seed_batch(*g._concat(reads))
+        printed = skipped = 0
+        for i in range(len(fwd)):
+            if i < len(rev):
+                n = min(len(fwd[i]), len(rev[i]))
+                ok, hf, tf, hr, tr = g.process_sequence_pair([r[1] for r in fwd[i][:n]], [r[1] for r in rev[i][:n]])
+                for j in np.nonzero(ok)[0]:
+                    keep = g.keep_pair(hf[j], tf[j], hr[j], tr[j])
+                    out["kept"].append(keep); out["high_fwd"].append(hf[j]); out["high_rev"].append(hr[j])
+                    out["total_fwd"].append(tf[j]); out["total_rev"].append(tr[j])
+                    printed += keep; skipped += (not keep)
+            else:
+                ok, hf, tf = g.process_sequence_single([r[1] for r in fwd[i]])
+                for j in np.nonzero(ok)[0]:
+                    keep = g.keep_single(hf[j], tf[j])
+                    out["kept"].append(keep); out["high_fwd"].append(hf[j]); out["high_rev"].append(-1)
+                    out["total_fwd"].append(tf[j]); out["total_rev"].append(-1)
+                    printed += keep; skipped += (not keep)
+            out["per_file"].append([len(out["kept"]), printed, skipped, g.unique_kmers])
+        res = {key: np.array(v, dtype=np.int32) for key, v in out.items() if key != "per_file"}
+        res["kept"] = res["kept"].astype(np.uint8)
+        res["per_file"] = out["per_file"]
+        res["unique"] = g.unique_kmers
+        res["stats"] = g.stats()
+    return res
+
+
+@pytest.mark.parametrize("name", sorted(META))
+def test_golden_cases(nk, oracle_lib, name):
+    """Every captured reference run: the HIP path equals the exact-count oracle counter for counter, and equals
+    the reference's own keep/skip decisions (and its counters where its table had no collisions)."""
+    cfg = parse_args(META[name]["args"])
+    gold = golden_arrays(name)
+    want = drive_oracle(cfg, model=Oracle.EXACT)
+    got = drive_gpu(nk, cfg)
+    for f in ("kept",) + FIELDS:
+        np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    assert got["unique"] == want["unique"]
+    assert got["per_file"] == want["per_file"]
+    np.testing.assert_array_equal(got["kept"], gold["kept"])
+    assert int(got["kept"].sum()) == META[name]["final"]["printed"]
+
+
+def random_reads(rng, n, lo, hi, alphabet=b"ACGT", n_rate=0.0):
+    reads = []
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    for _ in range(n):
+        r = al[rng.integers(0, len(al), rng.integers(lo, hi + 1))].copy()
+        if n_rate:
+            r[rng.random(len(r)) < n_rate] = ord("N")
+        reads.append(r.tobytes())
+    return reads
+
+
+@pytest.mark.parametrize("k,depth,canonical,chunk", [
+    (5, 2, False, 0), (5, 3, True, 64), (7, 5, False, 1024), (9, 100, True, 4096), (15, 3, False, 64),
+    (16, 4, True, 0), (17, 3, False, 128), (21, 2, True, 0), (25, 4, True, 1024), (31, 3, False, 64), (31, 50, True, 0),
+])
+def test_random_reads_small_keyspace(nk, oracle_lib, k, depth, canonical, chunk):
+    """Low-complexity reads (2-3 letter alphabets, repeats) make the same k-mers recur inside reads and
+    across chunks, so depth crossings land inside reads, at chunk edges and in the middle of batches."""
+    rng = np.random.default_rng(1000 + k * 7 + depth)
+    reads = random_reads(rng, 600, k, 4 * k + 40, b"AC") + random_reads(rng, 600, k, 200, b"ACGT", 0.01) \
+        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"G" * 64, b"C" * 33, b"N" * 40] * 3
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    o = oracle_lib(k, depth, canonical)
+    want = [o.read(r) for r in reads]
+    assert all(w[0] == 1 for w in want)
+    with nk.KmerNormaliser(k, depth, 0.9, canonical, chunk_bases=chunk, max_batch_reads=512, max_batch_bases=40000) as g:
+        ok, high, total = g.process_sequence_single(reads)
+        assert ok.all()
+        np.testing.assert_array_equal(high, [w[1] for w in want])
+        np.testing.assert_array_equal(total, [w[2] for w in want])
+        assert g.unique_kmers == o.unique
+        st = g.stats()
+        assert st["kmers_counted"] == int(total.sum())
+
+
+def test_batch_cut_invariance(nk):
+    """The stream may be cut into batches anywhere: one batch, many batches and one read per batch agree."""
+    rng = np.random.default_rng(5)
+    reads = random_reads(rng, 400, 15, 120, b"ACG")
+    res = []
+    for max_reads, chunk in ((4096, 0), (37, 64), (1, 64)):
+        with nk.KmerNormaliser(11, 3, 0.9, True, chunk_bases=chunk, max_batch_reads=max_reads, max_batch_bases=1 << 16) as g:
+            res.append(g.process_sequence_single(reads)[1:] + (g.unique_kmers,))
+    for r in res[1:]:
+        np.testing.assert_array_equal(r[0], res[0][0])
+        np.testing.assert_array_equal(r[1], res[0][1])
+        assert r[2] == res[0][2]
+
+
+def test_short_reads_and_bad_bases(nk):
+    from nomalise_kmers_multi_large_amd import NkmlError
+    with nk.KmerNormaliser(15, 2) as g:
+        ok, hf, tf, hr, tr = g.process_sequence_pair([b"ACGTACGTACGTACGT", b"ACGT", b"ACGTACGTACGTACGT"],
+                                                     [b"ACGTACGTACGTACGTA", b"ACGTACGTACGTACGTA", b"ACG"])
+        assert ok.tolist() == [True, False, False]          # either mate < k: record not processed, nothing counted
+        assert (tf[0], tr[0]) == (2, 3)
+        assert g.unique_kmers == 3                            # the period-4 repeat has only 3 distinct 15-mers here
+        with pytest.raises(NkmlError) as e:                   # the reference exits on a non-ACGT base
+            g.process_sequence_single([b"ACGTACGTACGTACGTx"])
+        assert e.value.code == -4
+        with pytest.raises(NkmlError):
+            g.process_batch(np.frombuffer(b"ACGTACGTAC", dtype=np.uint8), np.array([0, 10], dtype=np.uint64))
+        # N is read as A: 6 all-A windows are skipped, the one ending in C counts
+        ok, h, t = g.process_sequence_single([b"N" * 20 + b"C"])
+        assert (int(h[0]), int(t[0])) == (0, 1)
+
+
+def test_keep_skip_edges(nk, oracle_lib):
+    with nk.KmerNormaliser(15, 2, 0.9) as g:
+        assert g.keep_single(0, 0) and not g.keep_single(9, 10) and g.keep_single(8, 10)
+        assert not g.keep_pair(0, 10, 10, 10) and g.keep_pair(8, 10, 0, 0)
+    rng = np.random.default_rng(11)
+    import torch
+    tot = rng.integers(0, 140, 20000).astype(np.int32)
+    hi = (rng.random(20000) * (tot + 1)).astype(np.int32)
+    for cov in (0.9, 0.96, 0.5, 0.001, 1.0):
+        with nk.KmerNormaliser(15, 2, cov) as g:
+            d_h = torch.from_numpy(hi).cuda(); d_t = torch.from_numpy(tot).cuda()
+            keep_p = torch.zeros(10000, dtype=torch.uint8, device="cuda")
+            keep_s = torch.zeros(20000, dtype=torch.uint8, device="cuda")
+            g.decide_device(d_h.data_ptr(), d_t.data_ptr(), 10000, True, keep_p.data_ptr())
+            g.decide_device(d_h.data_ptr(), d_t.data_ptr(), 20000, False, keep_s.data_ptr())
+            g.synchronize()
+            c = np.float32(cov)
+            want_s = [oracle_lib.keep_single(int(h), int(t), c) for h, t in zip(hi, tot)]
+            want_p = [oracle_lib.keep_pair(int(hi[2 * i]), int(tot[2 * i]), int(hi[2 * i + 1]), int(tot[2 * i + 1]), c)
+                      for i in range(10000)]
+            np.testing.assert_array_equal(keep_s.cpu().numpy().astype(bool), want_s)
+            np.testing.assert_array_equal(keep_p.cpu().numpy().astype(bool), want_p)
+            assert [g.keep_single(int(h), int(t)) for h, t in zip(hi[:2000], tot[:2000])] == want_s[:2000]
+
+
+def test_synthetic_pairs_device_path(nk, oracle_lib):
+    """150 bp synthetic pairs through the device-buffer entry point, in three batches, against the oracle;
+    also the staged entry points (kmerise -> count -> reduce) used by the sharded path give the same numbers."""
+    import torch
+    from nomalise_kmers_multi_large_amd import synth
+    n = 60000
+    blocks = list(synth.pair_blocks(n, seed=3, transcripts=60, block=20000))
+    o = oracle_lib(15, 100)
+    with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=40000, max_batch_bases=40000 * 150, chunk_bases=1 << 20) as g, \
+            nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=40000, max_batch_bases=40000 * 150) as g2:
+        for c1, c2 in blocks:
+            seq, off = synth.interleave(c1, c2)
+            want_h, want_t = o.batch(seq, off)
+            d_seq = torch.from_numpy(seq).cuda(); d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+            nr = len(off) - 1
+            d_h = torch.zeros(nr, dtype=torch.int32, device="cuda"); d_t = torch.zeros_like(d_h)
+            torch.cuda.synchronize()
+            g.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, len(seq), d_h.data_ptr(), d_t.data_ptr())
+            g.synchronize()
+            np.testing.assert_array_equal(d_h.cpu().numpy(), want_h)
+            np.testing.assert_array_equal(d_t.cpu().numpy(), want_t)
+            npos = (len(seq) + 15) // 16 * 16
+            d_keys = torch.zeros(npos, dtype=torch.int32, device="cuda")
+            d_flags = torch.zeros(npos, dtype=torch.uint8, device="cuda")
+            d_h2 = torch.zeros_like(d_h); d_t2 = torch.zeros_like(d_h)
+            torch.cuda.synchronize()
+            g2.kmerise_device(d_seq.data_ptr(), d_off.data_ptr(), nr, len(seq), d_keys.data_ptr())
+            g2.count_keys_device(d_keys.data_ptr(), npos, d_flags.data_ptr())
+            g2.reduce_reads_device(d_keys.data_ptr(), d_flags.data_ptr(), d_off.data_ptr(), nr, d_h2.data_ptr(), d_t2.data_ptr())
+            g2.synchronize()
+            np.testing.assert_array_equal(d_h2.cpu().numpy(), want_h)
+            np.testing.assert_array_equal(d_t2.cpu().numpy(), want_t)
+        assert g.unique_kmers == o.unique == g2.unique_kmers
+        st = g.stats()
+        assert st["crossing_kmers"] > 0 and st["kmers_saturated"] > 0  # both branches of the counting pass ran
+
+
+def test_table_dump_matches_oracle_counts(nk, oracle_lib):
+    rng = np.random.default_rng(9)
+    reads = random_reads(rng, 300, 20, 100, b"ACGT")
+    for k in (13, 19):
+        o = oracle_lib(k, 1000)
+        for r in reads:
+            o.read(r)
+        with nk.KmerNormaliser(k, 1000) as g:   # depth never reached: counts are exact occurrence counts
+            g.process_sequence_single(reads)
+            codes, counts, n = g.dump_table()
+            assert n == o.unique == len(codes)
+            assert all(o.count_of(int(c)) == int(v) for c, v in zip(codes[:5000], counts[:5000]))
