@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Benchmark of the k-mer coverage-normalisation hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 150 bp paired-end reads, k=15, depth=100, coverage=0.9, one
+device-resident k-mer table.  A step is one batch of --pairs-per-step read pairs (default 1 M) taken in stream
+order from the synthetic dataset; with the default 10 steps the timed region is the whole 10 M-pair
+dataset starting from an empty table.  Inputs are resident in HBM before the clock starts.  The per-step work is
+the complete hot path: pack -> k-merise -> count with exact stream-order ranks -> per-read reduce -> float32
+keep/skip decision.
+
+With N > 1 ranks the k-mer table is sharded by k-mer over the ranks: every rank k-merises its own slice of
+each step's pairs, keys travel to their owning rank with an all-to-all (RCCL), the owner counts them, the
+flags travel back, and the per-read counters are reduced where the reads live ("weak" scaling: each rank
+brings --pairs-per-step pairs per step).
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import nomalise_kmers_multi_large_amd as nk  # noqa: E402
+from nomalise_kmers_multi_large_amd import synth  # noqa: E402
+
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def algorithmic_bytes_per_pair(k):
+    """Per 150 bp pair: 2*150 sequence bytes in, 32 B (16-byte slot read + write) per k-mer occurrence,
+    16 B of counters out."""
+    w = READ_LEN - k + 1
+    return 2 * READ_LEN + 2 * w * 32 + 16
+
+
+def make_dataset(n_pairs, seed, pairs_per_step, first_pair=0):
+    """List of per-step (seq uint8[...], offsets int64[...]) host arrays."""
+    steps, buf1, buf2, have = [], [], [], 0
+    transcripts = max(50, n_pairs // 1000)
+    for c1, c2 in synth.pair_blocks(n_pairs, seed=seed, transcripts=transcripts, block=100000):
+        buf1.append(c1)
+        buf2.append(c2)
+        have += c1.shape[0]
+        while have >= pairs_per_step:
+            a1, a2 = np.concatenate(buf1), np.concatenate(buf2)
+            steps.append(synth.interleave(a1[:pairs_per_step], a2[:pairs_per_step]))
+            buf1, buf2 = [a1[pairs_per_step:]], [a2[pairs_per_step:]]
+            have -= pairs_per_step
+    if have:
+        steps.append(synth.interleave(np.concatenate(buf1), np.concatenate(buf2)))
+    return steps
+
+
+def cpu_baseline(sample_seq, sample_off, k, depth, cov, gpu_keep_prefix):
+    """Time the CPU side on a bounded sample of the same workload, on this host's cores.
+    Preferred: the compiled reference program (oracle/_ref/nkml_ref, --cpu 1, -m 16 so that its k=15 table is
+    collision-free); otherwise this repo's CPU restatement (oracle/nkml_oracle.so)."""
+    n_pairs = (len(sample_off) - 1) // 2
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "nkml_ref")
+    out = {"cores": 1, "sample": "first %d pairs of the timed dataset" % n_pairs, "unit": "read-pairs/s"}
+    if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
+        tmp = tempfile.mkdtemp(prefix="nkml_bench_")
+        try:
+            seq = sample_seq.reshape(-1, READ_LEN)
+            qual = b"F" * READ_LEN
+            with open(os.path.join(tmp, "s_1.fastq"), "wb") as f1, open(os.path.join(tmp, "s_2.fastq"), "wb") as f2:
+                for i in range(n_pairs):
+                    h = b"@SYN:%d " % i
+                    f1.write(h + b"1:N:0:ACGT\n" + seq[2 * i].tobytes() + b"\n+\n" + qual + b"\n")
+                    f2.write(h + b"2:N:0:ACGT\n" + seq[2 * i + 1].tobytes() + b"\n+\n" + qual + b"\n")
+            mem = ["-m", "16"] if k == 15 else (["-m", "4"] if k == 14 else [])
+            cmd = [ref_bin, "-f", "s_1.fastq", "-r", "s_2.fastq", "-k", str(k), "-d", str(depth), "-g", repr(cov)] + mem
+            t0 = time.time()
+            res = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False)
+            wall = time.time() - t0
+            text = res.stdout.decode("latin-1")
+            m_rt = re.search(r"Total runtime: ([\d.]+) seconds", text)
+            m_pr = re.search(r"Printed Records: ([\d,]+)", text)
+            m_un = re.search(r"Cumulative Max unique kmers in any thread: ([\d,]+)", text)
+            if res.returncode == 0 and m_rt and float(m_rt.group(1)) > 0:
+                runtime = float(m_rt.group(1))
+                out.update({"value": n_pairs / runtime, "kind": "reference",
+                            "sample": out["sample"] + "; reference --cpu 1 %s, its own 'Total runtime' %.0f s "
+                                      "(1 s clock, seeding pass and table copy excluded), wall %.1f s" % (" ".join(mem), runtime, wall)})
+                if m_pr:
+                    ref_printed = int(m_pr.group(1).replace(",", ""))
+                    out["parity"] = {"pairs": n_pairs, "reference_printed": ref_printed, "gpu_kept": int(gpu_keep_prefix),
+                                     "match": ref_printed == int(gpu_keep_prefix)}
+                if m_un:
+                    out["reference_unique_kmers"] = int(m_un.group(1).replace(",", ""))
+                return out
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    # restatement ("port"), single thread
+    sys.path.insert(0, ROOT)
+    from tests.helpers import Oracle
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "nkml_oracle.so"], check=False, stdout=subprocess.DEVNULL)
+    o = Oracle(k, depth)
+    t0 = time.time()
+    h, t = o.batch(sample_seq, sample_off.astype(np.uint64))
+    dt = time.time() - t0
+    r = np.where(t > 0, h.astype(np.float32) / np.maximum(t, 1).astype(np.float32), np.float32(0))
+    kept = int(((r[0::2] < np.float32(cov)) & (r[1::2] < np.float32(cov))).sum())
+    out.update({"value": n_pairs / dt, "kind": "port",
+                "parity": {"pairs": n_pairs, "oracle_kept": kept, "gpu_kept": int(gpu_keep_prefix), "match": kept == int(gpu_keep_prefix)}})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs-per-step", type=int, default=1000000)
+    ap.add_argument("--ksize", type=int, default=15)
+    ap.add_argument("--depth", type=int, default=100)
+    ap.add_argument("--coverage", type=float, default=0.9)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=300000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    k, depth, cov = args.ksize, args.depth, args.coverage
+    pps = args.pairs_per_step
+    n_pairs = args.steps * pps  # per rank
+
+    # every rank generates its own slice of the stream (different seed per rank: different reads of the same
+    # transcript mix would need a shared transcriptome; a per-rank dataset keeps the per-GPU work identical)
+    host_steps = make_dataset(n_pairs, args.seed + 1000 * rank, pps)
+    dev_steps = []
+    for seq, off in host_steps:
+        dev_steps.append((torch.from_numpy(seq).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev), len(off) - 1, len(seq)))
+
+    if world == 1:
+        from nomalise_kmers_multi_large_amd.normaliser import KmerNormaliser
+        eng = KmerNormaliser(k, depth, cov, canonical=False, device=local_rank, max_batch_reads=2 * pps,
+                             max_batch_bases=2 * pps * READ_LEN, profile=True)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream: library kernels and torch ops stay ordered
+        d_high = torch.zeros(2 * pps, dtype=torch.int32, device=dev)
+        d_total = torch.zeros_like(d_high)
+        d_keep = torch.zeros(pps, dtype=torch.uint8, device=dev)
+        kept_per_step = torch.zeros(len(dev_steps), dtype=torch.int64, device=dev)
+
+        def step(i):
+            s, o, nr, nb = dev_steps[i]
+            eng.process_device(s.data_ptr(), o.data_ptr(), nr, nb, d_high.data_ptr(), d_total.data_ptr())
+            eng.decide_device(d_high.data_ptr(), d_total.data_ptr(), nr // 2, True, d_keep.data_ptr())
+
+        def sync():
+            eng.synchronize()
+            torch.cuda.synchronize()
+    else:
+        from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
+        eng = ShardedNormaliser(k, depth, cov, canonical=False, device=local_rank, max_pairs=pps, read_len=READ_LEN, profile=True)
+        d_keep = torch.zeros(pps, dtype=torch.uint8, device=dev)
+
+        def step(i):
+            s, o, nr, nb = dev_steps[i]
+            eng.process_step(s, o, nr, nb, d_keep)
+
+        def sync():
+            eng.synchronize()
+            torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # warmup: the first steps of the stream, then forget the counts so the timed region starts from an empty table
+    for i in range(min(args.warmup, len(dev_steps))):
+        step(i)
+    sync()
+    eng.reset()
+    sync()
+
+    keeps = []
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        if world == 1:
+            keeps.append(d_keep[: dev_steps[i][2] // 2].sum(dtype=torch.int64))  # torch stream; ordered by the sync below
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    st = eng.stats()
+    total_pairs = n_pairs * world
+    value = total_pairs / elapsed
+    unique = st["unique_kmers"]
+    if dist is not None:
+        u = torch.tensor([unique], dtype=torch.int64, device=dev)
+        dist.all_reduce(u)
+        unique = int(u.item())
+
+    if rank == 0:
+        count_ms = st["count_kernel_ms"]
+        launches = max(1, st["count_kernel_launches"])
+        occ = st["kmers_counted"]
+        alg_bytes_per_launch = 32.0 * occ / launches
+        avg_ms = count_ms / launches
+        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_count_kernel.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if pmc.get("ksize") == k and pmc.get("pairs_per_step") == pps:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "read-pairs/sec at k=%d, 150 bp PE (+ unique-kmers/sec)" % k,
+            "value": value,
+            "unit": "read-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d depth=%d coverage=%g, %s" % (
+                n_pairs, k, depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (RCCL all-to-all)" % world),
+                "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d" % world},
+            "unique_kmers": unique,
+            "unique_kmers_per_s": unique / elapsed,
+            "kmer_occurrences_per_s": occ * world / elapsed,
+            "algorithmic_GBps_whole_path": value * algorithmic_bytes_per_pair(k) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "k_count_direct" if k <= 16 else "k_count_hashed", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+            "table": {"saturated_fraction": st["kmers_saturated"] / max(1, occ), "crossing_kmers": st["crossing_kmers"],
+                      "crossing_occurrences": st["crossing_occurrences"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample_pairs = min(args.cpu_sample_pairs, pps)
+            sample_pairs -= sample_pairs % 100000 if sample_pairs >= 100000 else 0
+            seq0, off0 = host_steps[0]
+            sseq = seq0[: sample_pairs * 2 * READ_LEN]
+            soff = off0[: sample_pairs * 2 + 1]
+            # decisions of the GPU run on the same prefix (step 0 starts from the empty table, as the CPU run does)
+            eng.reset()
+            s, o, nr, nb = dev_steps[0]
+            eng.process_device(s.data_ptr(), o.data_ptr(), nr, nb, d_high.data_ptr(), d_total.data_ptr())
+            eng.decide_device(d_high.data_ptr(), d_total.data_ptr(), nr // 2, True, d_keep.data_ptr())
+            sync()
+            gpu_kept_prefix = int(d_keep[:sample_pairs].sum().item())
+            result["cpu_baseline"] = cpu_baseline(sseq, soff, k, depth, cov, gpu_kept_prefix)
+            result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"] if result["cpu_baseline"].get("value") else None
+        elif world == 1:
+            result["cpu_baseline"] = None
+        result["kept_pairs"] = int(sum(int(x.item()) for x in keeps)) if keeps else None
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

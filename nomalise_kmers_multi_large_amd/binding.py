@@ -53,6 +53,12 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own HIP runtime; when torch is going to be used in this process it has to be the
+    # one that initialises the GPU, so it is imported before the library pulls in libamdhip64.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise ImportError("%s is missing: build it with `make -C nomalise_kmers_multi_large_amd/csrc` "
