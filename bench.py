@@ -166,13 +166,13 @@ def main():
         eng.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream: library kernels and torch ops stay ordered
         d_high = torch.zeros(2 * pps, dtype=torch.int32, device=dev)
         d_total = torch.zeros_like(d_high)
-        d_keep = torch.zeros(pps, dtype=torch.uint8, device=dev)
-        kept_per_step = torch.zeros(len(dev_steps), dtype=torch.int64, device=dev)
+        d_keep_all = torch.zeros((len(dev_steps), pps), dtype=torch.uint8, device=dev)  # one row of decisions per step
+        d_keep = d_keep_all[0]
 
         def step(i):
             s, o, nr, nb = dev_steps[i]
             eng.process_device(s.data_ptr(), o.data_ptr(), nr, nb, d_high.data_ptr(), d_total.data_ptr())
-            eng.decide_device(d_high.data_ptr(), d_total.data_ptr(), nr // 2, True, d_keep.data_ptr())
+            eng.decide_device(d_high.data_ptr(), d_total.data_ptr(), nr // 2, True, d_keep_all[i].data_ptr())
 
         def sync():
             eng.synchronize()
@@ -201,17 +201,15 @@ def main():
     eng.reset()
     sync()
 
-    keeps = []
     barrier()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        if world == 1:
-            keeps.append(d_keep[: dev_steps[i][2] // 2].sum(dtype=torch.int64))  # torch stream; ordered by the sync below
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    kept_pairs = int(d_keep_all.sum(dtype=torch.int64).item()) if world == 1 else None
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -281,12 +279,12 @@ def main():
             eng.process_device(s.data_ptr(), o.data_ptr(), nr, nb, d_high.data_ptr(), d_total.data_ptr())
             eng.decide_device(d_high.data_ptr(), d_total.data_ptr(), nr // 2, True, d_keep.data_ptr())
             sync()
-            gpu_kept_prefix = int(d_keep[:sample_pairs].sum().item())
+            gpu_kept_prefix = int(d_keep[:sample_pairs].sum(dtype=torch.int64).item())
             result["cpu_baseline"] = cpu_baseline(sseq, soff, k, depth, cov, gpu_kept_prefix)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"] if result["cpu_baseline"].get("value") else None
         elif world == 1:
             result["cpu_baseline"] = None
-        result["kept_pairs"] = int(sum(int(x.item()) for x in keeps)) if keeps else None
+        result["kept_pairs"] = kept_pairs
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

@@ -9,7 +9,7 @@
 //   flags     u8  [16*words]           per base position: NKML_FLAG_*
 // The table lives for the whole run:
 //   k <= 16 : counts u32[4^k] (direct-addressed, what the reference degenerates to when capacity == 4^k,
-//             normalise_kmers_multi_large.c:676-684), sat/cross bitmaps of 4^k bits each
+//             normalise_kmers_multi_large.c:676-684), saturation bitmap of 4^k bits
 //   k >  16 : 16-byte slots {key u64, count u32, state u32}, open addressing with linear probing
 //             (same slot size as kmer_t, normalise_kmers_multi_large.c:156-161)
 //
@@ -19,7 +19,8 @@
 //   (1) k-mers whose count was already >= depth-1 when the pass began ("saturated", one bit per k-mer, frozen
 //       during the pass) are high whatever the order, and need no update at all;
 //   (2) every other occurrence does one atomic add; a k-mer can only be mis-ranked if its count reaches depth
-//       inside this pass ("crossing"); the occurrence that sees the count become depth flags the k-mer;
+//       inside this pass ("crossing"); the occurrence that sees the count become depth lists the k-mer and sets
+//       its bit in a small hashed filter (2 MiB, stays in L2; false positives only cost a little extra work);
 //   (3) occurrences of crossing k-mers (a small set: each k-mer crosses once per run) are collected, sorted by
 //       (k-mer, position) and given their true ranks: with m occurrences in the pass and final count F, the
 //       i-th in stream order (0-based) has rank F - m + i + 1.
@@ -39,7 +40,17 @@ namespace {
 constexpr uint32_t FLAG_NONE = NKML_FLAG_NONE, FLAG_HIGH = NKML_FLAG_HIGH, FLAG_LOW = NKML_FLAG_LOW;
 constexpr uint32_t SEEDED_BIT = 0x80000000u; // direct table: k-mer present through seeding (count part may be 0)
 constexpr uint32_t COUNT_MASK = 0x7fffffffu;
-constexpr uint32_t ST_SAT = 1u, ST_CROSS = 2u, ST_SEEDED = 4u; // hashed table slot state bits
+constexpr uint32_t ST_SAT = 1u; // hashed table slot state bit
+constexpr int FILTER_BITS = 24;  // crossing filter: 2^24 bits = 2 MiB
+constexpr uint32_t FILTER_WORDS = 1u << (FILTER_BITS - 5);
+
+__device__ __forceinline__ uint32_t filter_index(uint32_t id) { return (id * 0x9E3779B1u) >> (32 - FILTER_BITS); }
+__device__ __forceinline__ uint32_t filter_index(unsigned long long id)
+{
+    return (uint32_t)((id * 0x9E3779B97F4A7C15ull) >> (64 - FILTER_BITS));
+}
+__device__ __forceinline__ void filter_set(uint32_t *__restrict__ filter, uint32_t h) { atomicOr(&filter[h >> 5], 1u << (h & 31)); }
+__device__ __forceinline__ bool filter_test(const uint32_t *__restrict__ filter, uint32_t h) { return (filter[h >> 5] >> (h & 31)) & 1u; }
 
 struct alignas(256) Counters {
     unsigned long long unique;    // distinct k-mers stored (hash_table->used)
@@ -47,7 +58,8 @@ struct alignas(256) Counters {
     unsigned long long saturated; // of those, answered by the saturation bit
     unsigned int n_sat_new;       // S list length (count reached depth-1 in this pass)
     unsigned int n_cross;         // X list length (count reached depth in this pass)
-    unsigned int n_occ;           // E list length (occurrences of crossing k-mers)
+    unsigned int n_occ;           // E list length (occurrences of crossing k-mers, whole batch)
+    unsigned long long total_cross; // crossing k-mers since reset
     unsigned int bad_bases;       // bytes outside ACGTN seen by the packer
     unsigned int probe_overflow;  // hashed table: a probe sequence wrapped (table full) - must stay 0
 };
@@ -213,16 +225,53 @@ __device__ __forceinline__ void flush_tallies(uint32_t uniq, uint32_t counted, u
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Appends to the device-wide lists go through a per-workgroup list in LDS that is emptied with one global
+// atomic per flush: a single counter word takes under 100 M atomics a second chip-wide, far less than the
+// rate at which saturation / crossing events and crossing occurrences turn up.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int CAP>
+struct BlockList {
+    T items[CAP];
+    uint32_t n;
+    uint32_t base;
+};
+
+template <typename T, int CAP>
+__device__ __forceinline__ void blocklist_push(BlockList<T, CAP> &bl, T v, T *__restrict__ global_list, unsigned int *global_n)
+{
+    uint32_t at = atomicAdd(&bl.n, 1u);
+    if (at < CAP) bl.items[at] = v;
+    else global_list[atomicAdd(global_n, 1u)] = v; // LDS list full: rare, go straight to the global list
+}
+
+// all threads of the workgroup must call this (it synchronises)
+template <typename T, int CAP>
+__device__ __forceinline__ void blocklist_flush(BlockList<T, CAP> &bl, T *__restrict__ global_list, unsigned int *global_n)
+{
+    __syncthreads();
+    uint32_t n = bl.n < CAP ? bl.n : CAP;
+    if (threadIdx.x == 0 && n) bl.base = atomicAdd(global_n, n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) global_list[bl.base + i] = bl.items[i];
+    __syncthreads();
+    if (threadIdx.x == 0) bl.n = 0;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K3 (k <= 16): count one chunk of keys against the direct-addressed table.  Restates store_kmer's insert /
 // increment (normalise_kmers_multi_large.c:948-1008) and the high test (:1494-1497).  Four keys per lane: the
 // four bitmap gathers, then the four atomic adds, are independent and in flight together.
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_count_direct(const uint32_t *__restrict__ keys, uint64_t n4, uint8_t *__restrict__ flags,
                                                       uint32_t *__restrict__ counts, const uint32_t *__restrict__ sat,
-                                                      uint32_t *__restrict__ cross, uint32_t depth, int count_saturated,
+                                                      uint32_t *__restrict__ filter, uint32_t depth, int count_saturated,
                                                       Counters *ctr, uint32_t *__restrict__ list_sat,
                                                       uint32_t *__restrict__ list_cross)
 {
+    __shared__ BlockList<uint32_t, 1024> bl_sat, bl_cross;
+    if (threadIdx.x == 0) { bl_sat.n = 0; bl_cross.n = 0; }
+    __syncthreads();
     uint64_t stride = (uint64_t)gridDim.x * 256;
     uint32_t uniq = 0, counted = 0, nsat = 0;
     for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
@@ -253,15 +302,17 @@ __global__ void __launch_bounds__(256) k_count_direct(const uint32_t *__restrict
             if (fl[u] == FLAG_LOW) {
                 uint32_t c1 = (old[u] & COUNT_MASK) + 1;
                 if (old[u] == 0) uniq++;
-                if (c1 == depth - 1) list_sat[atomicAdd(&ctr->n_sat_new, 1u)] = key[u];
+                if (c1 == depth - 1) blocklist_push(bl_sat, key[u], list_sat, &ctr->n_sat_new);
                 if (c1 == depth) {
-                    list_cross[atomicAdd(&ctr->n_cross, 1u)] = key[u];
-                    atomicOr(&cross[key[u] >> 5], 1u << (key[u] & 31));
+                    blocklist_push(bl_cross, key[u], list_cross, &ctr->n_cross);
+                    filter_set(filter, filter_index(key[u]));
                 }
             }
         }
         reinterpret_cast<uint32_t *>(flags)[q] = fl[0] | (fl[1] << 8) | (fl[2] << 16) | (fl[3] << 24);
     }
+    blocklist_flush(bl_sat, list_sat, &ctr->n_sat_new);
+    blocklist_flush(bl_cross, list_cross, &ctr->n_cross);
     flush_tallies(uniq, counted, nsat, ctr);
 }
 
@@ -279,41 +330,44 @@ __global__ void __launch_bounds__(256) k_seed_direct(const uint32_t *__restrict_
     flush_tallies(uniq, 0, 0, ctr);
 }
 
-// K4a: collect the occurrences of crossing k-mers of this chunk: (id << posbits) | position-in-chunk.
-template <typename KEY>
-__device__ __forceinline__ void append_occurrence(bool pred, uint64_t value, unsigned long long *__restrict__ occ, Counters *ctr)
-{
-    unsigned long long m = __ballot(pred);
-    if (m == 0) return;
-    int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&ctr->n_occ, (unsigned int)__popcll(m));
-    base = __shfl(base, leader);
-    if (pred) occ[base + __popcll(m & ((1ull << lane) - 1))] = value;
-}
+// K4a: right after a chunk's counting pass, collect the occurrences of the k-mers that crossed in it:
+// (id << posbits) | position-in-batch.  The filter screens, the count (>= depth, and the occurrence was not
+// saturated when the pass began) confirms, so the list is exact.  Nothing runs if no k-mer crossed.
+// Hits are staged in LDS and flushed whenever another full iteration might not fit.
+constexpr int OCC_CAP = 3072;
+using OccList = BlockList<unsigned long long, OCC_CAP>;
 
 __global__ void __launch_bounds__(256) k_collect_direct(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ flags,
-                                                        uint64_t n4, const uint32_t *__restrict__ cross, int posbits,
+                                                        uint64_t n4, uint64_t pos_base, const uint32_t *__restrict__ filter,
+                                                        const uint32_t *__restrict__ counts, uint32_t depth, int posbits,
                                                         unsigned long long *__restrict__ occ, Counters *ctr)
 {
+    __shared__ OccList bl;
+    if (ctr->n_cross == 0) return; // uniform: written by the previous kernel
+    if (threadIdx.x == 0) bl.n = 0;
+    __syncthreads();
     uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint64_t n4r = (n4 + stride - 1) / stride * stride; // every lane runs the same trip count (ballots inside)
+    uint64_t n4r = (n4 + stride - 1) / stride * stride; // same trip count for every lane: the flush synchronises
     for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < n4r; q += stride) {
-        uint32_t f4 = 0;
-        uint4 kv = make_uint4(0, 0, 0, 0);
         if (q < n4) {
-            f4 = reinterpret_cast<const uint32_t *>(flags)[q];
-            if (f4 & 0x02020202u) kv = reinterpret_cast<const uint4 *>(keys)[q];
-        }
-        uint32_t key[4] = {kv.x, kv.y, kv.z, kv.w};
+            uint32_t f4 = reinterpret_cast<const uint32_t *>(flags)[q];
+            if (f4 & 0x02020202u) {
+                uint4 kv = reinterpret_cast<const uint4 *>(keys)[q];
+                uint32_t key[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            bool low = ((f4 >> (8 * u)) & 0xffu) == FLAG_LOW;
-            bool hit = low && ((cross[key[u] >> 5] >> (key[u] & 31)) & 1u);
-            append_occurrence<uint32_t>(hit, ((uint64_t)key[u] << posbits) | (q * 4 + u), occ, ctr);
+                for (int u = 0; u < 4; u++) {
+                    bool low = ((f4 >> (8 * u)) & 0xffu) == FLAG_LOW;
+                    if (low && filter_test(filter, filter_index(key[u])) && (counts[key[u]] & COUNT_MASK) >= depth)
+                        blocklist_push(bl, ((unsigned long long)key[u] << posbits) | (pos_base + q * 4 + u), occ, &ctr->n_occ);
+                }
+            }
         }
+        __syncthreads();
+        uint32_t fill = bl.n;
+        __syncthreads(); // every lane has read the same fill level before anyone pushes again
+        if (fill > OCC_CAP - 1024) blocklist_flush(bl, occ, &ctr->n_occ);
     }
+    blocklist_flush(bl, occ, &ctr->n_occ);
 }
 
 // K4b: exact stream-order ranks for the sorted occurrences.  occ is sorted by (id, position); an id's group is
@@ -347,18 +401,23 @@ struct HashedTable {
     __device__ uint32_t count_of(unsigned long long id) const { return slots[id].count; }
 };
 
-// K4c: between passes, k-mers that reached depth-1 become saturated; crossing marks are cleared.
-__global__ void __launch_bounds__(256) k_apply_direct(const uint32_t *__restrict__ list_sat, uint32_t n_sat,
-                                                      const uint32_t *__restrict__ list_cross, uint32_t n_cross,
-                                                      uint32_t *__restrict__ sat, uint32_t *__restrict__ cross)
+// K4c: between passes, k-mers whose count reached depth-1 or depth become saturated.  List lengths are read
+// on the device, so the host never waits for them.
+__global__ void __launch_bounds__(256) k_apply_direct(const uint32_t *__restrict__ list_sat, const uint32_t *__restrict__ list_cross,
+                                                      uint32_t *__restrict__ sat, const Counters *ctr)
 {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_sat) { uint32_t k = list_sat[i]; atomicOr(&sat[k >> 5], 1u << (k & 31)); }
-    if (i < n_cross) {
-        uint32_t k = list_cross[i];
-        atomicOr(&sat[k >> 5], 1u << (k & 31));
-        atomicAnd(&cross[k >> 5], ~(1u << (k & 31)));
-    }
+    uint32_t n_sat = ctr->n_sat_new, n_cross = ctr->n_cross;
+    uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_sat; i += stride) { uint32_t k = list_sat[i]; atomicOr(&sat[k >> 5], 1u << (k & 31)); }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_cross; i += stride) { uint32_t k = list_cross[i]; atomicOr(&sat[k >> 5], 1u << (k & 31)); }
+}
+
+// end of a chunk: the two list lengths restart at zero, the running totals keep them for the statistics
+__global__ void k_end_chunk(Counters *ctr)
+{
+    ctr->total_cross += ctr->n_cross;
+    ctr->n_sat_new = 0;
+    ctr->n_cross = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -398,10 +457,14 @@ __device__ __forceinline__ uint64_t find_or_insert(Slot *__restrict__ slots, uin
 
 __global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *__restrict__ keys, uint64_t n, uint8_t *__restrict__ flags,
                                                       unsigned long long *__restrict__ slot_of, Slot *__restrict__ slots,
-                                                      uint64_t cap_mask, uint32_t depth, int count_saturated, Counters *ctr,
+                                                      uint64_t cap_mask, uint32_t *__restrict__ filter, uint32_t depth,
+                                                      int count_saturated, Counters *ctr,
                                                       unsigned long long *__restrict__ list_sat,
                                                       unsigned long long *__restrict__ list_cross)
 {
+    __shared__ BlockList<unsigned long long, 512> bl_sat, bl_cross;
+    if (threadIdx.x == 0) { bl_sat.n = 0; bl_cross.n = 0; }
+    __syncthreads();
     uint64_t stride = (uint64_t)gridDim.x * 256;
     uint32_t uniq = 0, counted = 0, nsat = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -422,16 +485,18 @@ __global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *
                     fl = FLAG_LOW;
                     slot_of[i] = h;
                     uint32_t c1 = atomicAdd(&slots[h].count, 1u) + 1;
-                    if (c1 == depth - 1) list_sat[atomicAdd(&ctr->n_sat_new, 1u)] = h;
+                    if (c1 == depth - 1) blocklist_push(bl_sat, (unsigned long long)h, list_sat, &ctr->n_sat_new);
                     if (c1 == depth) {
-                        list_cross[atomicAdd(&ctr->n_cross, 1u)] = h;
-                        atomicOr(&slots[h].state, ST_CROSS);
+                        blocklist_push(bl_cross, (unsigned long long)h, list_cross, &ctr->n_cross);
+                        filter_set(filter, filter_index((unsigned long long)h));
                     }
                 }
             }
         }
         flags[i] = (uint8_t)fl;
     }
+    blocklist_flush(bl_sat, list_sat, &ctr->n_sat_new);
+    blocklist_flush(bl_cross, list_cross, &ctr->n_cross);
     flush_tallies(uniq, counted, nsat, ctr);
 }
 
@@ -452,32 +517,38 @@ __global__ void __launch_bounds__(256) k_seed_hashed(const unsigned long long *_
 }
 
 __global__ void __launch_bounds__(256) k_collect_hashed(const uint8_t *__restrict__ flags, const unsigned long long *__restrict__ slot_of,
-                                                        uint64_t n, const Slot *__restrict__ slots, int posbits,
+                                                        uint64_t n, uint64_t pos_base, const uint32_t *__restrict__ filter,
+                                                        const Slot *__restrict__ slots, uint32_t depth, int posbits,
                                                         unsigned long long *__restrict__ occ, Counters *ctr)
 {
+    __shared__ OccList bl;
+    if (ctr->n_cross == 0) return;
+    if (threadIdx.x == 0) bl.n = 0;
+    __syncthreads();
     uint64_t stride = (uint64_t)gridDim.x * 256;
     uint64_t nr = (n + stride - 1) / stride * stride;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nr; i += stride) {
-        bool hit = false;
-        unsigned long long h = 0;
         if (i < n && flags[i] == FLAG_LOW) {
-            h = slot_of[i];
-            hit = (slots[h].state & ST_CROSS) != 0;
+            unsigned long long h = slot_of[i];
+            if (filter_test(filter, filter_index(h)) && slots[h].count >= depth)
+                blocklist_push(bl, (h << posbits) | (pos_base + i), occ, &ctr->n_occ);
         }
-        append_occurrence<unsigned long long>(hit, (h << posbits) | i, occ, ctr);
+        __syncthreads();
+        uint32_t fill = bl.n;
+        __syncthreads();
+        if (fill > OCC_CAP - 256) blocklist_flush(bl, occ, &ctr->n_occ);
     }
+    blocklist_flush(bl, occ, &ctr->n_occ);
 }
 
-__global__ void __launch_bounds__(256) k_apply_hashed(const unsigned long long *__restrict__ list_sat, uint32_t n_sat,
-                                                      const unsigned long long *__restrict__ list_cross, uint32_t n_cross,
-                                                      Slot *__restrict__ slots)
+__global__ void __launch_bounds__(256) k_apply_hashed(const unsigned long long *__restrict__ list_sat,
+                                                      const unsigned long long *__restrict__ list_cross, Slot *__restrict__ slots,
+                                                      const Counters *ctr)
 {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_sat) atomicOr(&slots[list_sat[i]].state, ST_SAT);
-    if (i < n_cross) {
-        atomicOr(&slots[list_cross[i]].state, ST_SAT);
-        atomicAnd(&slots[list_cross[i]].state, ~ST_CROSS);
-    }
+    uint32_t n_sat = ctr->n_sat_new, n_cross = ctr->n_cross;
+    uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_sat; i += stride) atomicOr(&slots[list_sat[i]].state, ST_SAT);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_cross; i += stride) atomicOr(&slots[list_cross[i]].state, ST_SAT);
 }
 
 // Growth (expand_local_hash_table, normalise_kmers_multi_large.c:1055-1108): every stored key moves to a table
@@ -504,13 +575,10 @@ __global__ void __launch_bounds__(256) k_rehash(const Slot *__restrict__ old_slo
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K5: per read, high = flags equal to HIGH, total = non-zero keys (sequence_to_hash's two counters,
-// normalise_kmers_multi_large.c:1486, 1496).  One wavefront per read, 64 positions per step.
-// ------------------------------------------------------------------------------------------------------
-template <typename KEY>
-__global__ void __launch_bounds__(256) k_reduce_reads(const KEY *__restrict__ keys, const uint8_t *__restrict__ flags,
-                                                      const uint64_t *__restrict__ offsets, uint32_t n_reads,
-                                                      int32_t *__restrict__ high, int32_t *__restrict__ total)
+// K5: per read, high = flags equal to HIGH, total = flags that are not NONE, i.e. windows with a non-zero code
+// (sequence_to_hash's two counters, normalise_kmers_multi_large.c:1486, 1496).  One wavefront per read.
+__global__ void __launch_bounds__(256) k_reduce_reads(const uint8_t *__restrict__ flags, const uint64_t *__restrict__ offsets,
+                                                      uint32_t n_reads, int32_t *__restrict__ high, int32_t *__restrict__ total)
 {
     uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_reads) return;
@@ -518,8 +586,9 @@ __global__ void __launch_bounds__(256) k_reduce_reads(const KEY *__restrict__ ke
     uint64_t a = offsets[r], b = offsets[r + 1];
     uint32_t h = 0, t = 0;
     for (uint64_t p = a + lane; p < b; p += 64) {
-        h += flags[p] == FLAG_HIGH;
-        t += keys[p] != 0;
+        uint32_t f = flags[p];
+        h += f == FLAG_HIGH;
+        t += f != FLAG_NONE;
     }
     h = wave_sum(h);
     t = wave_sum(t);
@@ -587,7 +656,8 @@ struct nkml_ctx {
 
     // table
     uint32_t *counts;       // direct
-    uint32_t *sat, *cross;  // direct bitmaps
+    uint32_t *sat;          // direct: saturation bitmap
+    uint32_t *filter;       // crossing filter (both table kinds)
     Slot *slots;            // hashed
     uint64_t capacity;      // slots / counters
     uint64_t resizes;
@@ -621,7 +691,7 @@ struct nkml_ctx {
 
     // stats
     uint64_t crossing_kmers, crossing_occ;
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev[2 * 64];  // start/stop pairs around the counting kernel of up to 64 chunks per batch
     double count_ms;
     uint64_t count_launches, count_keys;
 };
@@ -667,11 +737,11 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->counts, c->capacity * sizeof(uint32_t)));
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, hipMalloc(&c->sat, bm));
-        HIPCHK(c, hipMalloc(&c->cross, bm));
     } else {
         c->capacity = default_hashed_capacity(c->cfg.memory_gb);
         HIPCHK(c, hipMalloc(&c->slots, c->capacity * sizeof(Slot)));
     }
+    HIPCHK(c, hipMalloc(&c->filter, FILTER_WORDS * sizeof(uint32_t)));
     return NKML_OK;
 }
 
@@ -681,10 +751,10 @@ int clear_table(nkml_ctx *c)
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, hipMemsetAsync(c->counts, 0, c->capacity * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->sat, 0, bm, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->cross, 0, bm, c->stream));
     } else {
         HIPCHK(c, hipMemsetAsync(c->slots, 0, c->capacity * sizeof(Slot), c->stream));
     }
+    HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->crossing_kmers = c->crossing_occ = 0;
     c->count_ms = 0;
@@ -746,17 +816,20 @@ int run_kmerise(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, ui
     return NKML_OK;
 }
 
-// K3 + K4 over keys [0, n) in chunks; n is a multiple of 16.
+// K3 + K4 over keys [0, n) in chunks; n is a multiple of 16.  Per chunk: count, collect the occurrences of the
+// k-mers that crossed, make the newly saturated k-mers visible to the next chunk - all enqueued without
+// waiting.  One wait per batch, for the number of crossing occurrences, then sort + rank them.
 int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, bool seeding)
 {
     const uint32_t depth = (uint32_t)c->cfg.depth;
-    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0;
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
+    int rc;
+    if ((rc = ensure_capacity(c, n)) != NKML_OK) return rc;
+    if ((n >> c->posbits) != 0 && n != (1ull << c->posbits)) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
+    int n_ev = 0;
+    uint64_t keys_timed = 0;
     for (uint64_t a = 0; a < n; a += c->chunk) {
         uint64_t len = n - a < c->chunk ? n - a : c->chunk;
-        int rc;
-        if (!c->direct) {
-            if ((rc = ensure_capacity(c, len)) != NKML_OK) return rc;
-        }
         if (seeding) {
             if (c->direct)
                 hipLaunchKernelGGL(k_seed_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len, c->counts, c->d_ctr);
@@ -764,69 +837,65 @@ int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, boo
                 hipLaunchKernelGGL(k_seed_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, c->slots,
                                    c->capacity - 1, c->d_ctr);
             HIPCHK(c, hipGetLastError());
-            if ((rc = fetch_counters(c)) != NKML_OK) return rc;
             continue;
         }
-        if (profile) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+        const bool timed = profile && n_ev < 64;
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
         if (c->direct) {
             hipLaunchKernelGGL(k_count_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len / 4, d_flags + a, c->counts,
-                               c->sat, c->cross, depth, 0, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
+                               c->sat, c->filter, depth, 0, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
         } else {
             hipLaunchKernelGGL(k_count_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, d_flags + a,
-                               c->d_slot_of, c->slots, c->capacity - 1, depth, 0, c->d_ctr, (unsigned long long *)c->d_list_sat,
+                               c->d_slot_of, c->slots, c->capacity - 1, c->filter, depth, 0, c->d_ctr, (unsigned long long *)c->d_list_sat,
                                (unsigned long long *)c->d_list_cross);
         }
         HIPCHK(c, hipGetLastError());
-        if (profile) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        if ((rc = fetch_counters(c)) != NKML_OK) return rc;
-        if (profile) {
-            float ms = 0;
-            HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-            c->count_ms += ms;
-            c->count_launches++;
-            c->count_keys += len;
+        if (timed) {
+            HIPCHK(c, hipEventRecord(c->ev[2 * n_ev + 1], c->stream));
+            n_ev++;
+            keys_timed += len;
         }
-        if (c->h_ctr->probe_overflow) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
-        uint32_t n_sat = c->h_ctr->n_sat_new, n_cross = c->h_ctr->n_cross;
-        if (n_cross) {
-            if (c->direct)
-                hipLaunchKernelGGL(k_collect_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, d_flags + a, len / 4, c->cross,
-                                   c->posbits, c->d_occ, c->d_ctr);
-            else
-                hipLaunchKernelGGL(k_collect_hashed, GRID_PERSIST, 256, 0, c->stream, d_flags + a, c->d_slot_of, len, c->slots, c->posbits,
-                                   c->d_occ, c->d_ctr);
-            HIPCHK(c, hipGetLastError());
-            if ((rc = fetch_counters(c)) != NKML_OK) return rc;
-            uint32_t n_occ = c->h_ctr->n_occ;
-            if (n_occ) {
-                int idbits = 0;
-                while (idbits < 64 && (c->capacity - 1) >> idbits) idbits++;
-                size_t tmp = c->sort_tmp_bytes;
-                HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, tmp, c->d_occ, c->d_occ_sorted, (size_t)n_occ, 0u,
-                                                   (unsigned)(c->posbits + idbits), c->stream));
-                if (c->direct)
-                    hipLaunchKernelGGL((k_rank<DirectTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
-                                       DirectTable{c->counts}, depth, d_flags + a);
-                else
-                    hipLaunchKernelGGL((k_rank<HashedTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
-                                       HashedTable{c->slots}, depth, d_flags + a);
-                HIPCHK(c, hipGetLastError());
-            }
-            c->crossing_kmers += n_cross;
-            c->crossing_occ += n_occ;
+        if (c->direct) {
+            hipLaunchKernelGGL(k_collect_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, d_flags + a, len / 4, a, c->filter,
+                               c->counts, depth, c->posbits, c->d_occ, c->d_ctr);
+            hipLaunchKernelGGL(k_apply_direct, 256, 256, 0, c->stream, (const uint32_t *)c->d_list_sat, (const uint32_t *)c->d_list_cross, c->sat,
+                               c->d_ctr);
+        } else {
+            hipLaunchKernelGGL(k_collect_hashed, GRID_PERSIST, 256, 0, c->stream, d_flags + a, c->d_slot_of, len, a, c->filter, c->slots, depth,
+                               c->posbits, c->d_occ, c->d_ctr);
+            hipLaunchKernelGGL(k_apply_hashed, 256, 256, 0, c->stream, (const unsigned long long *)c->d_list_sat,
+                               (const unsigned long long *)c->d_list_cross, c->slots, c->d_ctr);
         }
-        if (n_sat || n_cross) {
-            uint32_t m = n_sat > n_cross ? n_sat : n_cross;
-            if (c->direct)
-                hipLaunchKernelGGL(k_apply_direct, blocks_for(m), 256, 0, c->stream, (const uint32_t *)c->d_list_sat, n_sat,
-                                   (const uint32_t *)c->d_list_cross, n_cross, c->sat, c->cross);
-            else
-                hipLaunchKernelGGL(k_apply_hashed, blocks_for(m), 256, 0, c->stream, (const unsigned long long *)c->d_list_sat, n_sat,
-                                   (const unsigned long long *)c->d_list_cross, n_cross, c->slots);
-            HIPCHK(c, hipGetLastError());
-            // the three list lengths restart at zero for the next pass
-            HIPCHK(c, hipMemsetAsync(&c->d_ctr->n_sat_new, 0, 3 * sizeof(unsigned int), c->stream));
-        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_end_chunk, 1, 1, 0, c->stream, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+    }
+    if ((rc = fetch_counters(c)) != NKML_OK) return rc; // the batch's one wait
+    if (c->h_ctr->probe_overflow) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
+    for (int i = 0; i < n_ev; i++) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
+        c->count_ms += ms;
+    }
+    c->count_launches += n_ev;
+    c->count_keys += keys_timed;
+    uint32_t n_occ = c->h_ctr->n_occ;
+    if (n_occ) {
+        int idbits = 0;
+        while (idbits < 64 && (c->capacity - 1) >> idbits) idbits++;
+        size_t tmp = c->sort_tmp_bytes;
+        HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, tmp, c->d_occ, c->d_occ_sorted, (size_t)n_occ, 0u, (unsigned)(c->posbits + idbits),
+                                           c->stream));
+        if (c->direct)
+            hipLaunchKernelGGL((k_rank<DirectTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
+                               DirectTable{c->counts}, depth, d_flags);
+        else
+            hipLaunchKernelGGL((k_rank<HashedTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
+                               HashedTable{c->slots}, depth, d_flags);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->n_occ, 0, sizeof(unsigned int), c->stream));
+        c->crossing_occ += n_occ;
     }
     return NKML_OK;
 }
@@ -835,12 +904,8 @@ int run_reduce(nkml_ctx *c, const void *d_keys, const uint8_t *d_flags, const ui
                int32_t *d_total)
 {
     if (n_reads == 0) return NKML_OK;
-    if (c->key_bytes == 4)
-        hipLaunchKernelGGL((k_reduce_reads<uint32_t>), blocks_for(n_reads, 4), 256, 0, c->stream, (const uint32_t *)d_keys, d_flags, d_offsets,
-                           n_reads, d_high, d_total);
-    else
-        hipLaunchKernelGGL((k_reduce_reads<unsigned long long>), blocks_for(n_reads, 4), 256, 0, c->stream, (const unsigned long long *)d_keys,
-                           d_flags, d_offsets, n_reads, d_high, d_total);
+    (void)d_keys;
+    hipLaunchKernelGGL(k_reduce_reads, blocks_for(n_reads, 4), 256, 0, c->stream, d_flags, d_offsets, n_reads, d_high, d_total);
     HIPCHK(c, hipGetLastError());
     return NKML_OK;
 }
@@ -908,10 +973,10 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     chunk = (chunk + 63) & ~63u;
     if (chunk > (1u << 30)) chunk = 1u << 30;
     c->chunk = chunk;
-    c->posbits = 0;
-    while ((1ull << c->posbits) < chunk) c->posbits++;
     c->max_words = (cfg->max_batch_bases + 15) / 16;
     const uint64_t npos = c->max_words * 16;
+    c->posbits = 0;
+    while ((1ull << c->posbits) < npos) c->posbits++;
 
 #define CREATE_CHK(call)                                                   \
     do {                                                                   \
@@ -930,8 +995,8 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
 
     CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;
-    CREATE_HIP(hipEventCreate(&c->ev0));
-    CREATE_HIP(hipEventCreate(&c->ev1));
+    if (cfg->flags & NKML_F_PROFILE)
+        for (int i = 0; i < 2 * 64; i++) CREATE_HIP(hipEventCreate(&c->ev[i]));
     CREATE_HIP(hipMalloc(&c->d_ctr, sizeof(Counters)));
     CREATE_HIP(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
     memset(c->h_ctr, 0, sizeof(Counters));
@@ -948,11 +1013,11 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
     CREATE_HIP(hipMalloc(&c->d_list_sat, per_chunk * c->key_bytes));
     CREATE_HIP(hipMalloc(&c->d_list_cross, per_chunk * c->key_bytes));
-    CREATE_HIP(hipMalloc(&c->d_occ, per_chunk * sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc(&c->d_occ_sorted, per_chunk * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&c->d_occ, npos * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&c->d_occ_sorted, npos * sizeof(unsigned long long)));
     {
         size_t tmp = 0;
-        CREATE_HIP(rocprim::radix_sort_keys(nullptr, tmp, c->d_occ, c->d_occ_sorted, (size_t)per_chunk, 0u, 64u, c->stream));
+        CREATE_HIP(rocprim::radix_sort_keys(nullptr, tmp, c->d_occ, c->d_occ_sorted, (size_t)npos, 0u, 64u, c->stream));
         c->sort_tmp_bytes = tmp ? tmp : 256;
         CREATE_HIP(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes));
     }
@@ -973,7 +1038,7 @@ void nkml_destroy(nkml_ctx *c)
     if (!c) return;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->counts); hipFree(c->sat); hipFree(c->cross); hipFree(c->slots);
+    hipFree(c->counts); hipFree(c->sat); hipFree(c->filter); hipFree(c->slots);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_keys); hipFree(c->d_flags); hipFree(c->d_slot_of); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
@@ -983,8 +1048,8 @@ void nkml_destroy(nkml_ctx *c)
     if (c->h_offsets) hipHostFree(c->h_offsets);
     if (c->h_high) hipHostFree(c->h_high);
     if (c->h_total) hipHostFree(c->h_total);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (int i = 0; i < 2 * 64; i++)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1027,10 +1092,10 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     memset(out, 0, sizeof *out);
     out->unique_kmers = c->h_ctr->unique;
     out->capacity = c->capacity;
-    out->table_bytes = c->direct ? c->capacity * 4 + 2 * (c->capacity / 8) : c->capacity * sizeof(Slot);
+    out->table_bytes = c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
     out->kmers_counted = c->h_ctr->counted;
     out->kmers_saturated = c->h_ctr->saturated;
-    out->crossing_kmers = c->crossing_kmers;
+    out->crossing_kmers = c->h_ctr->total_cross;
     out->crossing_occurrences = c->crossing_occ;
     out->resizes = c->resizes;
     out->count_kernel_ms = c->count_ms;
