@@ -63,7 +63,10 @@ typedef struct nkml_config {
     uint32_t flags;           /* NKML_F_* */
 } nkml_config;
 
-#define NKML_F_PROFILE 1u     /* time the counting kernel with HIP events on the context's stream */
+#define NKML_F_PROFILE 1u      /* time the counting kernel with HIP events on the context's stream */
+#define NKML_F_EXACT_COUNTS 2u /* keep counting k-mers after they reach depth (only nkml_dump_table can tell: --print,
+                                  ref:354-385); costs one more atomic per saturated occurrence and, for k <= 16,
+                                  a second 4^k-entry counter array */
 
 typedef struct nkml_stats {
     uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */
@@ -127,6 +130,7 @@ int nkml_decide_device(nkml_ctx *ctx, const int32_t *d_high, const int32_t *d_to
  *   count   : keys in stream order -> one flag byte per key (NKML_FLAG_*), updating the table.  Restates
  *             store_kmer + the high test (ref:929-1053, 1486-1497) with exact stream-order ranks.
  *   reduce  : per read, high = number of NKML_FLAG_HIGH flags, total = number of non-zero keys. */
+/* d_keys / d_flags of the three stages hold one entry per base position rounded up to a multiple of 16. */
 int nkml_key_bytes(const nkml_ctx *ctx);
 int nkml_kmerise_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads,
                         uint64_t n_bases, void *d_keys);
@@ -139,7 +143,9 @@ int nkml_reduce_reads_device(nkml_ctx *ctx, const void *d_keys, const uint8_t *d
 #define NKML_FLAG_LOW 2u  /* counted, below depth */
 
 /* Table dump for --print (print_kmer_table, ref:354-385): up to max_entries (code, count) pairs of every
- * stored k-mer, unsorted like the reference; *n_entries gets the number available. Host arrays, synchronous. */
+ * stored k-mer, unsorted like the reference; *n_entries gets the number available. Host arrays, synchronous.
+ * Without NKML_F_EXACT_COUNTS a k-mer's count stops growing once it has reached depth-1 at the start of a
+ * counting pass (from then on every occurrence is high whatever the count). */
 int nkml_dump_table(nkml_ctx *ctx, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries);
 
 #ifdef __cplusplus

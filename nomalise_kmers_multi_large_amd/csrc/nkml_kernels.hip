@@ -40,7 +40,8 @@ namespace {
 constexpr uint32_t FLAG_NONE = NKML_FLAG_NONE, FLAG_HIGH = NKML_FLAG_HIGH, FLAG_LOW = NKML_FLAG_LOW;
 constexpr uint32_t SEEDED_BIT = 0x80000000u; // direct table: k-mer present through seeding (count part may be 0)
 constexpr uint32_t COUNT_MASK = 0x7fffffffu;
-constexpr uint32_t ST_SAT = 1u; // hashed table slot state bit
+constexpr uint32_t ST_SAT = 0x80000000u; // hashed table slot state: top bit = saturated, low 31 bits = occurrences
+                                          // counted after saturation (NKML_F_EXACT_COUNTS only)
 constexpr int FILTER_BITS = 24;  // crossing filter: 2^24 bits = 2 MiB
 constexpr uint32_t FILTER_WORDS = 1u << (FILTER_BITS - 5);
 
@@ -265,7 +266,7 @@ __device__ __forceinline__ void blocklist_flush(BlockList<T, CAP> &bl, T *__rest
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_count_direct(const uint32_t *__restrict__ keys, uint64_t n4, uint8_t *__restrict__ flags,
                                                       uint32_t *__restrict__ counts, const uint32_t *__restrict__ sat,
-                                                      uint32_t *__restrict__ filter, uint32_t depth, int count_saturated,
+                                                      uint32_t *__restrict__ filter, uint32_t depth, uint32_t *__restrict__ extra,
                                                       Counters *ctr, uint32_t *__restrict__ list_sat,
                                                       uint32_t *__restrict__ list_cross)
 {
@@ -290,7 +291,7 @@ __global__ void __launch_bounds__(256) k_count_direct(const uint32_t *__restrict
                 if (is_sat) {
                     fl[u] = FLAG_HIGH;
                     nsat++;
-                    if (count_saturated) atomicAdd(&counts[key[u]], 1u);
+                    if (extra) atomicAdd(&extra[key[u]], 1u); // counts[] stays frozen: the ranking pass relies on it
                 } else {
                     fl[u] = FLAG_LOW;
                     old[u] = atomicAdd(&counts[key[u]], 1u);
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *
                 if (state & ST_SAT) {
                     fl = FLAG_HIGH;
                     nsat++;
-                    if (count_saturated) atomicAdd(&slots[h].count, 1u);
+                    if (count_saturated) atomicAdd(&slots[h].state, 1u); // slot.count stays frozen for the ranking pass
                 } else {
                     fl = FLAG_LOW;
                     slot_of[i] = h;
@@ -616,7 +617,7 @@ __global__ void __launch_bounds__(256) k_decide(const int32_t *__restrict__ high
 }
 
 // table dump helpers
-__global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, uint64_t cap, unsigned long long *codes,
+__global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ extra, uint64_t cap, unsigned long long *codes,
                                                      uint32_t *cnts, uint64_t max_entries, unsigned long long *n_out)
 {
     uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -624,7 +625,7 @@ __global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict_
         uint32_t v = counts[i];
         if (v) {
             unsigned long long at = atomicAdd(n_out, 1ull);
-            if (at < max_entries) { codes[at] = i; cnts[at] = v & COUNT_MASK; }
+            if (at < max_entries) { codes[at] = i; cnts[at] = (v & COUNT_MASK) + (extra ? extra[i] : 0u); }
         }
     }
 }
@@ -636,7 +637,7 @@ __global__ void __launch_bounds__(256) k_dump_hashed(const Slot *__restrict__ sl
         Slot s = slots[i];
         if (s.key) {
             unsigned long long at = atomicAdd(n_out, 1ull);
-            if (at < max_entries) { codes[at] = s.key; cnts[at] = s.count; }
+            if (at < max_entries) { codes[at] = s.key; cnts[at] = s.count + (s.state & ~ST_SAT); }
         }
     }
 }
@@ -657,6 +658,7 @@ struct nkml_ctx {
     // table
     uint32_t *counts;       // direct
     uint32_t *sat;          // direct: saturation bitmap
+    uint32_t *extra;        // direct, NKML_F_EXACT_COUNTS: occurrences counted after saturation
     uint32_t *filter;       // crossing filter (both table kinds)
     Slot *slots;            // hashed
     uint64_t capacity;      // slots / counters
@@ -737,6 +739,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->counts, c->capacity * sizeof(uint32_t)));
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, hipMalloc(&c->sat, bm));
+        if (c->cfg.flags & NKML_F_EXACT_COUNTS) HIPCHK(c, hipMalloc(&c->extra, c->capacity * sizeof(uint32_t)));
     } else {
         c->capacity = default_hashed_capacity(c->cfg.memory_gb);
         HIPCHK(c, hipMalloc(&c->slots, c->capacity * sizeof(Slot)));
@@ -751,6 +754,7 @@ int clear_table(nkml_ctx *c)
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, hipMemsetAsync(c->counts, 0, c->capacity * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->sat, 0, bm, c->stream));
+        if (c->extra) HIPCHK(c, hipMemsetAsync(c->extra, 0, c->capacity * sizeof(uint32_t), c->stream));
     } else {
         HIPCHK(c, hipMemsetAsync(c->slots, 0, c->capacity * sizeof(Slot), c->stream));
     }
@@ -843,10 +847,11 @@ int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, boo
         if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
         if (c->direct) {
             hipLaunchKernelGGL(k_count_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len / 4, d_flags + a, c->counts,
-                               c->sat, c->filter, depth, 0, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
+                               c->sat, c->filter, depth, c->extra, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
         } else {
             hipLaunchKernelGGL(k_count_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, d_flags + a,
-                               c->d_slot_of, c->slots, c->capacity - 1, c->filter, depth, 0, c->d_ctr, (unsigned long long *)c->d_list_sat,
+                               c->d_slot_of, c->slots, c->capacity - 1, c->filter, depth, (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0, c->d_ctr,
+                               (unsigned long long *)c->d_list_sat,
                                (unsigned long long *)c->d_list_cross);
         }
         HIPCHK(c, hipGetLastError());
@@ -1038,7 +1043,7 @@ void nkml_destroy(nkml_ctx *c)
     if (!c) return;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->counts); hipFree(c->sat); hipFree(c->filter); hipFree(c->slots);
+    hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_keys); hipFree(c->d_flags); hipFree(c->d_slot_of); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
@@ -1241,7 +1246,7 @@ int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max
     HIPCHK(c, hipMalloc(&d_n, sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
     if (c->direct)
-        hipLaunchKernelGGL(k_dump_direct, GRID_PERSIST, 256, 0, c->stream, c->counts, c->capacity, d_codes, d_cnts, max_entries, d_n);
+        hipLaunchKernelGGL(k_dump_direct, GRID_PERSIST, 256, 0, c->stream, c->counts, c->extra, c->capacity, d_codes, d_cnts, max_entries, d_n);
     else
         hipLaunchKernelGGL(k_dump_hashed, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, d_codes, d_cnts, max_entries, d_n);
     HIPCHK(c, hipGetLastError());

@@ -1,0 +1,634 @@
+/*
+ * nkml_amd - command-line host of the MI355X k-mer coverage normaliser.
+ *
+ * Drop-in for the reference program's command line (normalise_kmers_multi_large.c, "ref"): same options
+ * (ref:543-565), same validation (ref:704-743), same input framing (4 lines per FASTQ record, 2 per FASTA
+ * record, ref:1572), same output files in the current directory (ref:834-850, 2286-2297), same kept-record bytes
+ * (sequence line with N rewritten to A, ref:1406, 1661-1665; FASTQ->FASTA header rule ref:852-876), same
+ * counters in the per-file and final report lines (ref:1911, 2415-2419).  The per-read work
+ * (ref:1551-1566 and everything below it) is done by the HIP library through the C ABI of nkml_hip.h:
+ * records are framed from the mmap'd inputs, their sequence lines staged into one batch, the batch counted
+ * on the GPU, and the float32 keep/skip test (ref:1641-1646) applied to the returned counters in input order.
+ *
+ * Differences, all deliberate:
+ *   --cpu is accepted and ignored: there is one shared k-mer table on the device, so the depth is not divided
+ *   by the thread count (ref:674) and there is a single output file pair named ..._thread0.fastq;
+ *   counts are exact (what the reference computes when its table has no collisions, i.e. -m 16 at k=15);
+ *   lines longer than 1023 bytes are an error instead of being split (ref:139, 394-409).
+ */
+#define _GNU_SOURCE
+#include <fcntl.h>
+#include <getopt.h>
+#include <locale.h>
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "nkml_hip.h"
+
+#define NKML_VERSION 20240823 /* the reference version this command line mirrors (ref:1) */
+#define MAX_LINE 1023         /* longest line the reference can hold (MAX_LINE_LENGTH - 1, ref:139) */
+#define MAX_CPUS 256          /* ref:142 */
+#define SEED_RECORDS 3e6      /* ref:146 */
+#define REF_DEFAULT_CAPACITY 67108879UL /* ref:137 */
+
+struct config {
+    char **fwd;
+    int n_fwd;
+    char **rev;
+    int n_rev;
+    int ksize, depth, cpus, verbose, debug, canonical, memory, single, doprint;
+    float coverage;
+    bool fastq_in, fastq_out;
+};
+static struct config cfg;
+
+struct mapped {
+    const char *data;
+    size_t size;
+};
+
+struct totals {
+    size_t processed, printed, skipped;
+};
+
+/* ---------------------------------------------------------------------------------------------------- */
+static void usage(void)
+{
+    fprintf(stderr,
+            "Usage:\n\n\t\tMandatory:\n"
+            "\t\t* --forward|-f file1 [file2+]\tList of forward (read1) sequence files\n"
+            "\t\t* --reverse|-r file1 [file2+]\tList of reverse (read2) sequence files\n"
+            "\n\t\tOptional:\n"
+            "\t\t[--single|-s] data are single ended, any --forward files not matched with --reverse are single-end\n"
+            "\t\t[--ksize|-k (integer 5-31; def. 15)]\tk-mer size\n"
+            "\t\t[--depth|-d (integer; def. 100)]\tcount at which a k-mer is tagged as high coverage\n"
+            "\t\t[--coverage|-g (float 0-1; def. 0.9)]\tproportion of a read's k-mers that must be high coverage to drop it\n"
+            "\t\t[--canonical|-c]\t\t\tmerge k-mers with their reverse complement\n"
+            "\t\t[--filetype|-t (fq|fa; def. fq)]\tinput format\n"
+            "\t\t[--outformat|-o (fq|fa; def. fq)]\toutput format\n"
+            "\t\t[--memory_start|-m (integer; def. 1)]\tGb of k-mer table to start with (k > 16; k <= 16 uses 4^k counters)\n"
+            "\t\t[--cpu|-p (int; def 1)]\t\t\taccepted for compatibility; the GPU path has one shared table\n"
+            "\t\t[--verbose|-e] [--debug|-b N] [--print|-P] [--version|-v] [--help|-h]\n");
+}
+
+static void add_files(char ***list, int *count, char *first, char **more, int *optind_io)
+{
+    /* ref:747-832: the option's own argument, then every following argv entry up to the next one starting
+     * with '-', each kept only if readable. */
+    char *cand = first;
+    for (;;) {
+        if (access(cand, R_OK) == 0) {
+            *list = realloc(*list, (size_t)(*count + 1) * sizeof(char *));
+            if (!*list) { fprintf(stderr, "Memory allocation failed\n"); exit(1); }
+            (*list)[(*count)++] = strdup(cand);
+        } else {
+            fprintf(stderr, "Warning: File '%s' does not exist or is not readable. Skipping.\n", cand);
+        }
+        if (*more == NULL || (*more)[0] == '-') break;
+        cand = *more++;
+        (*optind_io)++;
+    }
+}
+
+static bool parse_format(const char *s, bool *is_fastq)
+{
+    if (!strcasecmp(s, "fa") || !strcasecmp(s, "fasta") || !strcasecmp(s, "fsa") || !strcasecmp(s, "fas")) { *is_fastq = false; return true; }
+    if (!strcasecmp(s, "fq") || !strcasecmp(s, "fastq") || !strcasecmp(s, "fsq")) { *is_fastq = true; return true; }
+    return false;
+}
+
+static size_t pow4(int k) { return (size_t)1 << (2 * k); }
+
+/* initial_hash_size as the reference would report it (ref:416-422, 676-684); informational here */
+static size_t reference_capacity(int memory_gb, int cpus, int k)
+{
+    size_t cap = REF_DEFAULT_CAPACITY;
+    if (memory_gb > 0) {
+        size_t number = (size_t)((float)memory_gb * 1073741824.0f);
+        float total = (float)(number / 16);
+        size_t per_cpu = (size_t)(total / (float)cpus);
+        cap = (per_cpu % 2 == 0) ? per_cpu + 1 : per_cpu;
+    }
+    if (pow4(k) < cap) cap = pow4(k);
+    return cap;
+}
+
+static int parse_arguments(int argc, char **argv)
+{
+    cfg.coverage = 0.9f;
+    cfg.fastq_in = cfg.fastq_out = true;
+    cfg.cpus = 1;
+    cfg.ksize = 15;
+    cfg.depth = 100;
+    static struct option longopts[] = {
+        {"forward", required_argument, 0, 'f'}, {"reverse", required_argument, 0, 'r'}, {"ksize", required_argument, 0, 'k'},
+        {"depth", required_argument, 0, 'd'}, {"coverage", required_argument, 0, 'g'}, {"filetype", required_argument, 0, 't'},
+        {"outformat", required_argument, 0, 'o'}, {"cpu", required_argument, 0, 'p'}, {"memory_start", required_argument, 0, 'm'},
+        {"debug", required_argument, 0, 'b'}, {"verbose", no_argument, 0, 'e'}, {"help", no_argument, 0, 'h'},
+        {"canonical", no_argument, 0, 'c'}, {"version", no_argument, 0, 'v'}, {"single", no_argument, 0, 's'},
+        {"print", no_argument, 0, 'P'}, {0, 0, 0, 0}};
+    int opt, idx = 0;
+    while ((opt = getopt_long(argc, argv, "f:r:k:d:g:t:o:p:m:b:ehcvsP", longopts, &idx)) != -1) {
+        switch (opt) {
+        case 'P': cfg.doprint = 1; break;
+        case 's': cfg.single = 1; break;
+        case 'c': cfg.canonical = 1; break;
+        case 'm':
+            cfg.memory = atoi(optarg);
+            if (cfg.memory < 1) { printf("Memory cannot be less than 1 Gb %'d\n", cfg.memory); return 0; }
+            break;
+        case 'b': cfg.debug = atoi(optarg); break;
+        case 'h': usage(); exit(EXIT_SUCCESS);
+        case 'p': cfg.cpus = atoi(optarg); break;
+        case 'f': add_files(&cfg.fwd, &cfg.n_fwd, optarg, &argv[optind], &optind); break;
+        case 'r': add_files(&cfg.rev, &cfg.n_rev, optarg, &argv[optind], &optind); break;
+        case 'k': cfg.ksize = atoi(optarg); break;
+        case 'd': cfg.depth = atoi(optarg); break;
+        case 'g': cfg.coverage = (float)atof(optarg); break;
+        case 'v': printf("%d\n", NKML_VERSION); exit(EXIT_SUCCESS);
+        case 'e': cfg.verbose = 1; break;
+        case 't':
+            if (!parse_format(optarg, &cfg.fastq_in)) { printf("Input file format must be either fa or fq, not %s\n", optarg); return 0; }
+            break;
+        case 'o':
+            if (!parse_format(optarg, &cfg.fastq_out)) { printf("Output file format must be either fa or fq, not %s\n", optarg); return 0; }
+            break;
+        default: fprintf(stderr, "Unexpected error in option processing\n"); return 0;
+        }
+    }
+    if (cfg.verbose) {
+        printf("\nVERSION: %d, CMD: ", NKML_VERSION);
+        for (int i = 0; i < argc; i++) printf("%s ", argv[i]);
+        printf("\n\n");
+    }
+    if (cfg.cpus > 0 && cfg.ksize >= 1 && cfg.ksize <= 31) {
+        /* ref:676-685: the line reports the reference's own table sizing rule; the device table is sized by
+         * nkml_create (4^k counters for k <= 16, --memory_start GiB of 16-byte slots otherwise) */
+        size_t cap = cfg.memory > 0 ? reference_capacity(cfg.memory, cfg.cpus, 31) : REF_DEFAULT_CAPACITY;
+        float mem_per_cpu = (float)cap * 16 / 1073741824;
+        int total = cfg.memory;
+        if (pow4(cfg.ksize) < cap) {
+            cap = pow4(cfg.ksize);
+            mem_per_cpu = (float)cap * 16 / 1073741824;
+            total = (int)(mem_per_cpu * (float)cfg.cpus);
+        }
+        printf("Initial hash table size set to %'zu (maximum for k=%d is %'zu); memory ~ %'0.2f Gb for each of %d threads (~ %'d Gb total))\n\n",
+               cap, cfg.ksize, pow4(cfg.ksize), mem_per_cpu, cfg.cpus, total);
+    }
+    /* ref:704-743 */
+    if (cfg.n_fwd == 0 || (cfg.n_rev == 0 && !cfg.single)) {
+        fprintf(stderr, "Error: no fwd (%d) or reverse (%d) files provided\n", cfg.n_fwd, cfg.n_rev);
+        return 0;
+    }
+    if (!cfg.fastq_in && cfg.fastq_out) { fprintf(stderr, "Error: cannot request an output format of FASTQ when input is FASTA\n"); return 0; }
+    if (!cfg.single && cfg.n_fwd != cfg.n_rev) {
+        fprintf(stderr, "Error: Number of forward (%d) and reverse files (%d) must match\n", cfg.n_fwd, cfg.n_rev);
+        return 0;
+    }
+    if (cfg.cpus <= 0 || cfg.cpus > MAX_CPUS) {
+        fprintf(stderr, "Error: CPU count (%d) must be a positive integer and up to %d\n", cfg.cpus, MAX_CPUS);
+        return 0;
+    }
+    if (cfg.ksize < 5 || cfg.ksize > 31) { fprintf(stderr, "Error: Only kmer sizes (%d) of 5 to 31 are supported\n", cfg.ksize); return 0; }
+    if (cfg.coverage > 1 || cfg.coverage < 0.001) {
+        fprintf(stderr, "Error: Coverage (%3.f) is the proportion of the sequence covered by high kmers and must be between 0 and 1\n", cfg.coverage);
+        return 0;
+    }
+    if (cfg.depth < 2) {
+        fprintf(stderr, "Error: Depth (%d) is the number of times a kmer needs to be found before being flagged as high coverage, it must be above 1\n", cfg.depth);
+        return 0;
+    }
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+static struct mapped map_file(const char *name)
+{
+    struct mapped m = {NULL, 0};
+    int fd = open(name, O_RDONLY);
+    if (fd < 0) { perror("Error opening file"); return m; }
+    struct stat sb;
+    if (fstat(fd, &sb) < 0) { perror("Error getting file size"); close(fd); return m; }
+    m.size = (size_t)sb.st_size;
+    if (m.size == 0) { close(fd); m.data = ""; return m; }
+    void *p = mmap(NULL, m.size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { perror("Error mapping file"); m.size = 0; return m; }
+    madvise(p, m.size, MADV_SEQUENTIAL);
+    m.data = p;
+    return m;
+}
+
+static void unmap_file(struct mapped *m)
+{
+    if (m->data && m->size) munmap((void *)m->data, m->size);
+    m->data = NULL;
+    m->size = 0;
+}
+
+/* One record = `lines` lines starting at p.  Fills line starts/lengths, returns the position after the record,
+ * or NULL when fewer than `lines` lines remain.  The last line of a file may lack its newline (ref:394-409). */
+static const char *frame_record(const char *p, const char *end, int lines, const char **start, uint32_t *len)
+{
+    for (int i = 0; i < lines; i++) {
+        if (p >= end) return NULL;
+        const char *nl = memchr(p, '\n', (size_t)(end - p));
+        const char *e = nl ? nl : end;
+        if (e - p > MAX_LINE) {
+            fprintf(stderr, "FATAL: input line longer than %d bytes\n", MAX_LINE);
+            exit(EXIT_FAILURE);
+        }
+        start[i] = p;
+        len[i] = (uint32_t)(e - p);
+        p = nl ? nl + 1 : end;
+    }
+    return p;
+}
+
+static const uint8_t base_class[256] = {['A'] = 1, ['C'] = 1, ['G'] = 1, ['T'] = 1, ['N'] = 2}; /* valid_dna after N->A, ref:1144-1158, 1406 */
+
+static bool valid_bases(const char *s, uint32_t n)
+{
+    uint8_t ok = 1;
+    for (uint32_t i = 0; i < n; i++) ok &= (uint8_t)(base_class[(uint8_t)s[i]] != 0);
+    return ok;
+}
+
+static void fatal_sequence(const char *which, const char *s, uint32_t n)
+{
+    /* ref:1418, 1447, 1452 (the reference prints the N-masked line) */
+    char buf[MAX_LINE + 1];
+    for (uint32_t i = 0; i < n; i++) buf[i] = s[i] == 'N' ? 'A' : s[i];
+    buf[n] = 0;
+    fflush(NULL);
+    fprintf(stderr, "FATAL: %s sequence does not appear to be a DNA sequence\n%s\n\n", which, buf);
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* One batch in flight: staged sequence bytes + where each unit's record(s) start in the mmap'd files. */
+struct batch {
+    uint8_t *seq;
+    uint64_t *offsets;
+    const char **rec_fwd, **rec_rev; /* per unit (pair or single read) */
+    int32_t *high, *total;
+    uint32_t n_reads, n_units;
+    uint64_t n_bases;
+    uint32_t cap_reads;
+    uint64_t cap_bases;
+};
+
+static struct batch B;
+static nkml_ctx *ctx;
+static FILE *out_fwd, *out_rev;
+static struct totals tot;
+
+static void die_nkml(const char *what, int rc)
+{
+    fflush(NULL);
+    fprintf(stderr, "Error: %s: %s (%s)\n", what, nkml_strerror(rc), ctx ? nkml_last_error(ctx) : "");
+    exit(EXIT_FAILURE);
+}
+
+static void batch_alloc(uint32_t cap_reads, uint64_t cap_bases)
+{
+    B.cap_reads = cap_reads;
+    B.cap_bases = cap_bases;
+    B.seq = malloc(cap_bases);
+    B.offsets = malloc(((size_t)cap_reads + 1) * sizeof(uint64_t));
+    B.rec_fwd = malloc((size_t)cap_reads * sizeof(char *));
+    B.rec_rev = malloc((size_t)cap_reads * sizeof(char *));
+    B.high = malloc((size_t)cap_reads * sizeof(int32_t));
+    B.total = malloc((size_t)cap_reads * sizeof(int32_t));
+    if (!B.seq || !B.offsets || !B.rec_fwd || !B.rec_rev || !B.high || !B.total) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    B.offsets[0] = 0;
+}
+
+static inline void stage_read(const char *s, uint32_t n)
+{
+    memcpy(B.seq + B.n_bases, s, n);
+    B.n_bases += n;
+    B.offsets[++B.n_reads] = B.n_bases;
+}
+
+static void write_line_masked(FILE *f, const char *s, uint32_t n)
+{
+    if (memchr(s, 'N', n)) {
+        char buf[MAX_LINE + 1];
+        for (uint32_t i = 0; i < n; i++) buf[i] = s[i] == 'N' ? 'A' : s[i];
+        fwrite(buf, 1, n, f);
+    } else {
+        fwrite(s, 1, n, f);
+    }
+    fputc('\n', f);
+}
+
+/* Kept record, ref:1649-1666: the stored lines with the sequence line N-masked, or the FASTQ->FASTA form
+ * (ref:852-876: '>' header, "/1" or "/2" appended unless the header already ends with it). */
+static void write_record(FILE *f, const char *rec, const char *end, int lines, bool to_fasta, bool is_forward)
+{
+    const char *start[4];
+    uint32_t len[4];
+    frame_record(rec, end, lines, start, len);
+    if (to_fasta) {
+        const char *suffix = is_forward ? "/1" : "/2";
+        fputc('>', f);
+        if (len[0] > 1) fwrite(start[0] + 1, 1, len[0] - 1, f);
+        if (len[0] < 2 || memcmp(start[0] + len[0] - 2, suffix, 2) != 0) fwrite(suffix, 1, 2, f);
+        fputc('\n', f);
+        write_line_masked(f, start[1], len[1]);
+        return;
+    }
+    for (int i = 0; i < lines; i++) {
+        if (i == 1) write_line_masked(f, start[i], len[i]);
+        else { fwrite(start[i], 1, len[i], f); fputc('\n', f); }
+    }
+}
+
+static inline float ratio_f32(int32_t high, int32_t total)
+{
+    volatile float r = total > 0 ? (float)high / (float)total : 0.0f; /* ref:1641 */
+    return r;
+}
+
+/* Count the staged batch on the GPU, then decide and write in input order. */
+static void flush_batch(bool paired, const char *end_fwd, const char *end_rev, int lines)
+{
+    if (B.n_units == 0) return;
+    int rc = nkml_submit(ctx, B.seq, B.offsets, B.n_reads);
+    if (rc != NKML_OK) die_nkml("submit", rc);
+    rc = nkml_collect(ctx, B.high, B.total);
+    if (rc != NKML_OK) die_nkml("collect", rc);
+    const bool to_fasta = cfg.fastq_in && !cfg.fastq_out;
+    for (uint32_t u = 0; u < B.n_units; u++) {
+        bool keep;
+        tot.processed++;
+        if (paired) {
+            int32_t hf = B.high[2 * u], tf = B.total[2 * u], hr = B.high[2 * u + 1], tr = B.total[2 * u + 1];
+            keep = nkml_keep_pair(hf, tf, hr, tr, cfg.coverage) != 0; /* ref:1646 */
+            if (keep) {
+                write_record(out_fwd, B.rec_fwd[u], end_fwd, lines, to_fasta, true);
+                write_record(out_rev, B.rec_rev[u], end_rev, lines, to_fasta, false);
+                tot.printed++;
+            } else {
+                tot.skipped++;
+            }
+            if (cfg.debug > 1) /* ref:1677-1692 */
+                printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d;R:%d, Total kmers: F:%d;R:%d High count ratio: F:%.2f;R:%.2f\n",
+                       tot.processed, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, hr, tf, tr, ratio_f32(hf, tf), ratio_f32(hr, tr));
+        } else {
+            int32_t hf = B.high[u], tf = B.total[u];
+            keep = nkml_keep_single(hf, tf, cfg.coverage) != 0; /* ref:1992 */
+            if (keep) {
+                /* ref:1995-1999: the single-end FASTQ->FASTA branch builds the record and never writes it */
+                if (!to_fasta) write_record(out_fwd, B.rec_fwd[u], end_fwd, lines, false, true);
+                tot.printed++;
+            } else {
+                tot.skipped++;
+            }
+            if (cfg.debug > 1) /* ref:2017-2032 */
+                printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d, Total kmers: F:%d High count ratio: F:%.2f\n",
+                       tot.processed, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, tf, ratio_f32(hf, tf));
+        }
+    }
+    B.n_reads = B.n_units = 0;
+    B.n_bases = 0;
+}
+
+/* The record loop of process_thread_chunk_paired / _single (ref:1568-1770, 1921-2111) for one file (pair). */
+static void process_files(const struct mapped *fwd, const struct mapped *rev)
+{
+    const int lines = cfg.fastq_in ? 4 : 2;
+    const bool paired = rev != NULL;
+    const char *pf = fwd->data, *ef = fwd->data + fwd->size;
+    const char *pr = paired ? rev->data : NULL, *er = paired ? rev->data + rev->size : NULL;
+    const uint32_t K = (uint32_t)cfg.ksize;
+    const char *sf[4], *sr[4];
+    uint32_t lf[4], lr[4];
+    for (;;) {
+        const char *nf = frame_record(pf, ef, lines, sf, lf);
+        if (!nf) break;
+        const char *nr = NULL;
+        if (paired) {
+            nr = frame_record(pr, er, lines, sr, lr);
+            if (!nr) break;
+        }
+        /* is_valid_sequence_pair / _single, ref:1404-1457: lengths first, then the alphabet */
+        bool long_enough = lf[1] >= K && (!paired || lr[1] >= K);
+        if (long_enough) {
+            if (!valid_bases(sf[1], lf[1])) { flush_batch(paired, ef, er, lines); fatal_sequence("FWD", sf[1], lf[1]); exit(EXIT_FAILURE); }
+            if (paired && !valid_bases(sr[1], lr[1])) { flush_batch(paired, ef, er, lines); fatal_sequence("REV", sr[1], lr[1]); exit(EXIT_FAILURE); }
+            uint64_t need = (uint64_t)lf[1] + (paired ? lr[1] : 0);
+            if (B.n_reads + 2 > B.cap_reads || B.n_bases + need > B.cap_bases) flush_batch(paired, ef, er, lines);
+            B.rec_fwd[B.n_units] = pf;
+            stage_read(sf[1], lf[1]);
+            if (paired) {
+                B.rec_rev[B.n_units] = pr;
+                stage_read(sr[1], lr[1]);
+            }
+            B.n_units++;
+        } /* else: the record is dropped without being counted anywhere, ref:1630-1631 */
+        pf = nf;
+        if (paired) pr = nr;
+    }
+    flush_batch(paired, ef, er, lines);
+}
+
+/* seed_kmer_hash, ref:1322-1373: the first `limit` records whose sequence line is longer than k, of one file,
+ * enter the table with count 0.  Only newline-terminated lines count, as in the reference's byte loop. */
+static void seed_file(const char *name, int limit)
+{
+    if (cfg.verbose) printf("Seeding hash table with up to %'d records from file %s\n", limit, name);
+    struct mapped m = map_file(name);
+    if (!m.data) return;
+    const int lines = cfg.fastq_in ? 4 : 2;
+    const char *p = m.data, *end = m.data + m.size;
+    /* the reference only sees complete, newline-terminated lines: stop at the last newline */
+    while (end > p && end[-1] != '\n') end--;
+    const char *s[4];
+    uint32_t l[4];
+    int done = 0;
+    const uint32_t K = (uint32_t)cfg.ksize;
+    while (done < limit) {
+        const char *n = frame_record(p, end, lines, s, l);
+        if (!n) break;
+        if (l[1] > K) {
+            if (!valid_bases(s[1], l[1])) { fatal_sequence("FWD", s[1], l[1]); exit(EXIT_FAILURE); }
+            if (B.n_reads + 1 > B.cap_reads || B.n_bases + l[1] > B.cap_bases) {
+                int rc = nkml_seed(ctx, B.seq, B.offsets, B.n_reads);
+                if (rc != NKML_OK) die_nkml("seed", rc);
+                B.n_reads = 0; B.n_bases = 0;
+            }
+            stage_read(s[1], l[1]);
+            done++;
+        }
+        p = n;
+    }
+    if (B.n_reads) {
+        int rc = nkml_seed(ctx, B.seq, B.offsets, B.n_reads);
+        if (rc != NKML_OK) die_nkml("seed", rc);
+        B.n_reads = 0; B.n_bases = 0;
+    }
+    if (cfg.verbose) {
+        nkml_stats st;
+        nkml_get_stats(ctx, &st);
+        printf("%'d records with %'zu kmers seeded\n", done, (size_t)st.unique_kmers);
+    }
+    unmap_file(&m);
+}
+
+static char *output_name(const char *base, int k, int depth, int thread, const char *suffix)
+{
+    size_t n = strlen(base) + 64;
+    char *s = malloc(n);
+    if (!s) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    if (thread >= 0) snprintf(s, n, "%s.k%d_norm%d_thread%d.%s", base, k, depth, thread, suffix); /* ref:845 */
+    else snprintf(s, n, "%s.k%d_norm%d.%s", base, k, depth, suffix);
+    return s;
+}
+
+/* print_kmer_table, ref:354-385: kmer<TAB>count for every stored k-mer, unsorted */
+static void print_table(const char *identifier, int thread)
+{
+    uint64_t n = 0;
+    int rc = nkml_dump_table(ctx, NULL, NULL, 0, &n);
+    if (rc != NKML_OK) die_nkml("dump", rc);
+    uint64_t *codes = malloc((n ? n : 1) * sizeof(uint64_t));
+    uint32_t *counts = malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!codes || !counts) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    uint64_t got = 0;
+    rc = nkml_dump_table(ctx, codes, counts, n, &got);
+    if (rc != NKML_OK) die_nkml("dump", rc);
+    if (got < n) n = got;
+    char base[32];
+    snprintf(base, sizeof base, "output_kmer%s", identifier);
+    char *name = output_name(base, cfg.ksize, cfg.depth, thread, "tsv");
+    FILE *f = fopen(name, "w");
+    if (f) {
+        char kmer[40];
+        for (uint64_t i = 0; i < n; i++) {
+            uint64_t e = codes[i];
+            for (int j = cfg.ksize - 1; j >= 0; j--) { kmer[j] = "ACGT"[e & 3]; e >>= 2; } /* decode_kmer_plain, ref:1128-1136 */
+            kmer[cfg.ksize] = 0;
+            fprintf(f, "%s\t%u\n", kmer, counts[i]);
+        }
+        fclose(f);
+    }
+    free(name); free(codes); free(counts);
+}
+
+int main(int argc, char **argv)
+{
+    setlocale(LC_ALL, "");
+    if (!parse_arguments(argc, argv)) { usage(); return 1; }
+
+    nkml_config nc;
+    memset(&nc, 0, sizeof nc);
+    nc.ksize = cfg.ksize;
+    nc.depth = cfg.depth;
+    nc.canonical = cfg.canonical;
+    nc.device = getenv("NKML_DEVICE") ? atoi(getenv("NKML_DEVICE")) : 0;
+    nc.memory_gb = cfg.memory;
+    nc.max_batch_reads = 1u << 21;
+    nc.max_batch_bases = 400ull << 20;
+    if (getenv("NKML_BATCH_READS")) nc.max_batch_reads = (uint32_t)strtoul(getenv("NKML_BATCH_READS"), NULL, 10);
+    if (getenv("NKML_BATCH_BASES")) nc.max_batch_bases = strtoull(getenv("NKML_BATCH_BASES"), NULL, 10);
+    if (cfg.doprint) nc.flags |= NKML_F_EXACT_COUNTS;
+    int rc = nkml_create(&nc, &ctx);
+    if (rc != NKML_OK) die_nkml("cannot set up the GPU k-mer table", rc);
+    batch_alloc(nc.max_batch_reads, nc.max_batch_bases);
+
+    /* seeding pass over every input file, before any counting: ref:2242-2250 */
+    int seed_n = 1 + (int)(SEED_RECORDS / cfg.n_fwd);
+    if (!getenv("NKML_NO_SEED")) {
+        for (int i = 0; i < cfg.n_fwd; i++) {
+            seed_file(cfg.fwd[i], seed_n);
+            if (i < cfg.n_rev) seed_file(cfg.rev[i], seed_n);
+        }
+    }
+    if (cfg.doprint) print_table("_seeds", -1);
+
+    static char buf_f[1 << 20], buf_r[1 << 20];
+    char *name_f = output_name("output_forward", cfg.ksize, cfg.depth, 0, "fastq"); /* ref:2286: always .fastq */
+    out_fwd = fopen(name_f, "w");
+    if (!out_fwd) { fprintf(stderr, "Error opening file to write: %s\n", name_f); return EXIT_FAILURE; }
+    setvbuf(out_fwd, buf_f, _IOFBF, sizeof buf_f);
+    char *name_r = NULL;
+    if (cfg.n_rev != 0) { /* ref:2294 */
+        name_r = output_name("output_reverse", cfg.ksize, cfg.depth, 0, "fastq");
+        out_rev = fopen(name_r, "w");
+        if (!out_rev) { fprintf(stderr, "Error opening file to write: %s\n", name_r); return EXIT_FAILURE; }
+        setvbuf(out_rev, buf_r, _IOFBF, sizeof buf_r);
+    }
+
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    size_t max_unique = 0;
+    for (int i = 0; i < cfg.n_fwd; i++) {
+        struct mapped mf = map_file(cfg.fwd[i]), mr = {NULL, 0};
+        const bool paired = i < cfg.n_rev;
+        if (paired) {
+            printf("Processing file pair %d of %d: %s and %s\n", i + 1, cfg.n_fwd, cfg.fwd[i], cfg.rev[i]);
+            mr = map_file(cfg.rev[i]);
+            if (!mf.data || !mr.data) { fprintf(stderr, "Error memory mapping input files\n"); break; }
+        } else {
+            printf("Processing single-ended file %d of %d: %s\n", i + 1, cfg.n_fwd, cfg.fwd[i]);
+            if (!mf.data) { fprintf(stderr, "Error memory mapping input files\n"); break; }
+        }
+        const char first = cfg.fastq_in ? '@' : '>'; /* ref:2337-2361 */
+        if (mf.size == 0 || mf.data[0] != first) {
+            fprintf(stderr, "Input %s file %s starts with %c which is not expected\n", cfg.fastq_in ? "FASTQ" : "FASTA", cfg.fwd[i], mf.size ? mf.data[0] : ' ');
+            exit(EXIT_FAILURE);
+        }
+        if (paired && (mr.size == 0 || mr.data[0] != first)) {
+            fprintf(stderr, "Input %s file %s starts with %c which is not expected\n", cfg.fastq_in ? "FASTQ" : "FASTA", cfg.rev[i], mr.size ? mr.data[0] : ' ');
+            exit(EXIT_FAILURE);
+        }
+        struct timespec f0, f1;
+        clock_gettime(CLOCK_MONOTONIC, &f0);
+        size_t before = tot.processed;
+        process_files(&mf, paired ? &mr : NULL);
+        clock_gettime(CLOCK_MONOTONIC, &f1);
+        nkml_stats st;
+        if ((rc = nkml_get_stats(ctx, &st)) != NKML_OK) die_nkml("stats", rc);
+        if ((size_t)st.unique_kmers > max_unique) max_unique = (size_t)st.unique_kmers;
+        double secs = (double)(f1.tv_sec - f0.tv_sec) + 1e-9 * (double)(f1.tv_nsec - f0.tv_nsec);
+        /* ref:1752-1759 (rate measured with a finer clock than the reference's 1 s) and ref:1911 */
+        printf("Thread 0 - Processing rate: %'.0f sequences/s, processed %'zu pairs, printed: %'zu, skipped: %'zu, Unique kmers (all sequences; this thread): %'zu\n",
+               secs > 0 ? (double)(tot.processed - before) / secs : 0.0, tot.processed, tot.printed, tot.skipped, (size_t)st.unique_kmers);
+        printf("Cumulative file statistics: Processed %'zu, Printed %'zu, Skipped %'zu, Cumulative Max Unique Kmers in a thread: %'zu\n",
+               tot.processed, tot.printed, tot.skipped, (size_t)st.unique_kmers);
+        unmap_file(&mf);
+        if (paired) unmap_file(&mr);
+    }
+    fclose(out_fwd);
+    if (out_rev) fclose(out_rev);
+    if (cfg.doprint) print_table("", 0);
+
+    /* ref:2415-2419, 2438-2453 */
+    printf("\n--- Final Report ---\n");
+    printf("Processed Records: %'zu\n", tot.processed);
+    printf("Printed Records: %'zu\n", tot.printed);
+    printf("Skipped Records: %'zu\n", tot.skipped);
+    printf("Cumulative Max unique kmers in any thread: %'zu\n", max_unique);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double runtime = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    printf("Total runtime: %.2f seconds\n", runtime);
+    if (tot.processed > 0) {
+        if (cfg.n_rev != 0) printf("Overall processing rate: %'.0f sequence pairs per second\n", (double)tot.processed / runtime);
+        else printf("Overall processing rate: %'.0f sequences per second\n", (double)tot.processed / runtime);
+    } else {
+        printf("No data processed\n");
+    }
+    nkml_destroy(ctx);
+    free(name_f);
+    free(name_r);
+    return 0;
+}
