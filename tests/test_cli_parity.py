@@ -128,11 +128,18 @@ def test_cli_fatal_on_invalid_base(inputs_dir, tmp_path):
     bad = "@b\n" + "ACGT" * 5 + "acgt" + "ACGT" * 4 + "\n+\n" + "F" * 40 + "\n"
     (tmp_path / "f.fq").write_text(good + bad + good)
     (tmp_path / "r.fq").write_text(good + good + good)
+    # like the reference, the seeding pass (first 3 M records of every file) meets the bad read before any
+    # output file exists
     r = run_cli(["-f", "f.fq", "-r", "r.fq", "-d", "2"], str(tmp_path))
     assert r.returncode == 1
     assert b"FATAL: FWD sequence does not appear to be a DNA sequence" in r.stderr
-    # the record before the bad one was already decided and written, like the reference's flushed stdio buffers
-    assert (tmp_path / "output_forward.k15_norm2_thread0.fastq").read_text() == good
+    assert not (tmp_path / "output_forward.k15_norm2_thread0.fastq").exists()
+    # past the seeded prefix the record loop meets it: the records before it were already decided and written,
+    # like the reference's stdio buffers flushed by exit()
+    r = run_cli(["-f", "f.fq", "-r", "r.fq", "-d", "100"], str(tmp_path), env={"NKML_NO_SEED": "1"})
+    assert r.returncode == 1
+    assert b"FATAL: FWD sequence does not appear to be a DNA sequence" in r.stderr
+    assert (tmp_path / "output_forward.k15_norm100_thread0.fastq").read_text() == good
 
 
 @pytest.mark.gpu
