@@ -141,12 +141,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    # NKML_BENCH_REHEARSE=1: all ranks share GPU 0 and talk over gloo through host memory - a plumbing rehearsal on
+    # a one-GPU box, not a measurement (the JSON line says so)
+    rehearse = os.environ.get("NKML_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     k, depth, cov = args.ksize, args.depth, args.coverage
     pps = args.pairs_per_step
@@ -178,13 +186,17 @@ def main():
             eng.synchronize()
             torch.cuda.synchronize()
     else:
-        from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
-        eng = ShardedNormaliser(k, depth, cov, canonical=False, device=local_rank, max_pairs=pps, read_len=READ_LEN, profile=True)
-        d_keep = torch.zeros(pps, dtype=torch.uint8, device=dev)
+        from nomalise_kmers_multi_large_amd.sharded import HipShardEngine, ShardedNormaliser
+        engine = HipShardEngine(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN, profile=True)
+        eng = ShardedNormaliser(engine, stage_through_host=rehearse)
+        d_keep_all = torch.zeros((len(dev_steps), world, pps), dtype=torch.uint8, device=dev) if rank == 0 else None
 
         def step(i):
             s, o, nr, nb = dev_steps[i]
-            eng.process_step(s, o, nr, nb, d_keep)
+            _, _, gathered = eng.process_step(s, o, nr, nb)
+            if rank == 0:  # keep/skip for the whole step, in global stream order (rank-major)
+                for r, buf in enumerate(gathered):
+                    engine.decide(buf[0], buf[1], buf.shape[1] // 2, True, d_keep_all[i, r])
 
         def sync():
             eng.synchronize()
@@ -209,9 +221,10 @@ def main():
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    kept_pairs = int(d_keep_all.sum(dtype=torch.int64).item()) if world == 1 else None
+    kept_pairs = int(d_keep_all.sum(dtype=torch.int64).item()) if d_keep_all is not None else None
+    cdev = "cpu" if rehearse else dev
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -220,7 +233,7 @@ def main():
     value = total_pairs / elapsed
     unique = st["unique_kmers"]
     if dist is not None:
-        u = torch.tensor([unique], dtype=torch.int64, device=dev)
+        u = torch.tensor([unique], dtype=torch.int64, device=cdev)
         dist.all_reduce(u)
         unique = int(u.item())
 
@@ -252,7 +265,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
             "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d depth=%d coverage=%g, %s" % (
                 n_pairs, k, depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (RCCL all-to-all)" % world),
                 "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d" % world},

@@ -138,6 +138,19 @@ int nkml_count_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, u
 int nkml_reduce_reads_device(nkml_ctx *ctx, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets,
                              uint32_t n_reads, int32_t *d_high, int32_t *d_total);
 
+/* Sharding of the table over several devices (one context per device, each holding the counts of the keys it
+ * owns).  The reference never merges its per-thread tables (ref:2421); this exchange step is new.
+ *   owner_of      : the shard that owns a key (host function; the device kernels use the same rule).
+ *   route_keys    : stable partition of a key array by owner: d_send_keys/d_send_src get the non-zero keys grouped
+ *                   by destination shard, each group in stream order, with the base position each key came from;
+ *                   send_counts[s] (host) = keys for shard s.  Synchronous (the counts drive the all-to-all).
+ *   unroute_flags : flags returned by the owners, in send order, back to their base positions (others get 0). */
+int nkml_owner_of(uint64_t key, uint32_t n_shards);
+int nkml_route_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
+                           uint32_t *d_send_src, uint64_t *send_counts);
+int nkml_unroute_flags_device(nkml_ctx *ctx, const uint8_t *d_recv_flags, const uint32_t *d_send_src, uint64_t n_sent,
+                              uint8_t *d_flags, uint64_t n_keys);
+
 #define NKML_FLAG_NONE 0u /* no k-mer at this position */
 #define NKML_FLAG_HIGH 1u /* occurrence whose stream-order count is >= depth */
 #define NKML_FLAG_LOW 2u  /* counted, below depth */

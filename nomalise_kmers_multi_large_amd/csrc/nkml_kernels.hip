@@ -616,6 +616,75 @@ __global__ void __launch_bounds__(256) k_decide(const int32_t *__restrict__ high
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Sharded table (several GPUs): every key has an owning shard; keys are brought into destination order with a
+// stable partition, so that what an owner receives from each source is still in that source's stream order.
+// One wavefront owns ROUTE_TILE consecutive keys: pass 1 counts them per shard, an exclusive scan over
+// [shard][wave] turns the counts into start offsets, pass 2 places each key at offset + (number of earlier keys
+// of the same shard in the tile), computed with ballots.  Zero keys (no k-mer) are not sent.
+// ------------------------------------------------------------------------------------------------------
+constexpr int ROUTE_TILE = 1024;
+
+__host__ __device__ __forceinline__ uint32_t owner_of(unsigned long long key, uint32_t n_shards)
+{
+    return (uint32_t)(((key * 0x9E3779B97F4A7C15ull) >> 32) % n_shards);
+}
+
+template <typename KEY>
+__global__ void __launch_bounds__(256) k_route_count(const KEY *__restrict__ keys, uint64_t n, uint32_t n_shards, uint64_t n_waves,
+                                                     uint32_t *__restrict__ hist)
+{
+    uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= n_waves) return;
+    int lane = threadIdx.x & 63;
+    uint64_t base = wv * ROUTE_TILE;
+    for (uint32_t sh = lane; sh < n_shards; sh += 64) hist[(uint64_t)sh * n_waves + wv] = 0; // n_shards <= 64: one lane each
+    uint32_t mine = 0; // lane sh accumulates the count of shard sh
+    for (int it = 0; it < ROUTE_TILE / 64; it++) {
+        uint64_t i = base + it * 64 + lane;
+        unsigned long long key = i < n ? (unsigned long long)keys[i] : 0ull;
+        uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
+        for (uint32_t sh = 0; sh < n_shards; sh++) {
+            unsigned long long m = __ballot(own == sh);
+            if ((uint32_t)lane == sh) mine += (uint32_t)__popcll(m);
+        }
+    }
+    if ((uint32_t)lane < n_shards) hist[(uint64_t)lane * n_waves + wv] = mine;
+}
+
+template <typename KEY>
+__global__ void __launch_bounds__(256) k_route_scatter(const KEY *__restrict__ keys, uint64_t n, uint32_t n_shards, uint64_t n_waves,
+                                                       const uint32_t *__restrict__ offsets, KEY *__restrict__ send_keys,
+                                                       uint32_t *__restrict__ send_src)
+{
+    uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= n_waves) return;
+    int lane = threadIdx.x & 63;
+    uint64_t base = wv * ROUTE_TILE;
+    uint32_t next = (uint32_t)lane < n_shards ? offsets[(uint64_t)lane * n_waves + wv] : 0u; // lane sh: next free slot of shard sh
+    for (int it = 0; it < ROUTE_TILE / 64; it++) {
+        uint64_t i = base + it * 64 + lane;
+        unsigned long long key = i < n ? (unsigned long long)keys[i] : 0ull;
+        uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
+        uint32_t dst = 0;
+        for (uint32_t sh = 0; sh < n_shards; sh++) {
+            unsigned long long m = __ballot(own == sh);
+            uint32_t start = __shfl(next, (int)sh);
+            if (own == sh) dst = start + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            if ((uint32_t)lane == sh) next += (uint32_t)__popcll(m);
+        }
+        if (key) { send_keys[dst] = (KEY)key; send_src[dst] = (uint32_t)i; }
+    }
+}
+
+// flags that came back from the owners, in the order the keys were sent, go back to their base positions
+__global__ void __launch_bounds__(256) k_unroute_flags(const uint8_t *__restrict__ recv_flags, const uint32_t *__restrict__ send_src,
+                                                       uint64_t n_sent, uint8_t *__restrict__ flags)
+{
+    uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_sent; i += stride) flags[send_src[i]] = recv_flags[i];
+}
+
 // table dump helpers
 __global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ extra, uint64_t cap, unsigned long long *codes,
                                                      uint32_t *cnts, uint64_t max_entries, unsigned long long *n_out)
@@ -681,6 +750,12 @@ struct nkml_ctx {
     unsigned long long *d_occ, *d_occ_sorted;
     void *d_sort_tmp;
     size_t sort_tmp_bytes;
+
+    // routing scratch (sharded path), allocated on first use
+    uint32_t *d_route_hist, *d_route_off;
+    uint64_t route_entries;
+    void *d_route_tmp;
+    size_t route_tmp_bytes;
 
     Counters *d_ctr;
     Counters *h_ctr;        // pinned
@@ -1047,6 +1122,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_keys); hipFree(c->d_flags); hipFree(c->d_slot_of); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
+    hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
     hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
     if (c->h_seq) hipHostFree(c->h_seq);
@@ -1231,6 +1307,69 @@ int nkml_decide_device(nkml_ctx *c, const int32_t *d_high, const int32_t *d_tota
     HIPCHK(c, hipSetDevice(c->cfg.device));
     hipLaunchKernelGGL(k_decide, blocks_for(n_units), 256, 0, c->stream, d_high, d_total, n_units, paired, coverage, d_keep);
     HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int nkml_owner_of(uint64_t key, uint32_t n_shards) { return n_shards ? (int)owner_of(key, n_shards) : NKML_E_ARG; }
+
+int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
+                           uint32_t *d_send_src, uint64_t *send_counts)
+{
+    if (!c || !d_keys || !d_send_keys || !d_send_src || !send_counts || n_shards == 0 || n_shards > 64) return NKML_E_ARG;
+    if (n_keys >= (1ull << 32)) return fail(c, NKML_E_ARG, "too many keys for 32-bit source positions");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = 0;
+    if (n_keys == 0) return NKML_OK;
+    const uint64_t n_waves = (n_keys + ROUTE_TILE - 1) / ROUTE_TILE;
+    const uint64_t entries = n_waves * n_shards;
+    if (entries >= (1ull << 31)) return fail(c, NKML_E_ARG, "routing table too large");
+    if (entries + 1 > c->route_entries) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
+        c->d_route_hist = c->d_route_off = nullptr; c->d_route_tmp = nullptr;
+        c->route_entries = entries + 1;
+        HIPCHK(c, hipMalloc(&c->d_route_hist, c->route_entries * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->d_route_off, c->route_entries * sizeof(uint32_t)));
+        size_t tmp = 0;
+        HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, c->d_route_hist, c->d_route_off, 0u, (size_t)c->route_entries, rocprim::plus<uint32_t>(), c->stream));
+        c->route_tmp_bytes = tmp ? tmp : 256;
+        HIPCHK(c, hipMalloc(&c->d_route_tmp, c->route_tmp_bytes));
+    }
+    const uint32_t grid = blocks_for(n_waves, 4);
+    HIPCHK(c, hipMemsetAsync(c->d_route_hist + entries, 0, sizeof(uint32_t), c->stream)); // one extra entry: the scan's last output = total
+    if (c->key_bytes == 4)
+        hipLaunchKernelGGL((k_route_count<uint32_t>), grid, 256, 0, c->stream, (const uint32_t *)d_keys, n_keys, n_shards, n_waves, c->d_route_hist);
+    else
+        hipLaunchKernelGGL((k_route_count<unsigned long long>), grid, 256, 0, c->stream, (const unsigned long long *)d_keys, n_keys, n_shards, n_waves, c->d_route_hist);
+    HIPCHK(c, hipGetLastError());
+    size_t tmp = c->route_tmp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->d_route_tmp, tmp, c->d_route_hist, c->d_route_off, 0u, (size_t)(entries + 1), rocprim::plus<uint32_t>(), c->stream));
+    if (c->key_bytes == 4)
+        hipLaunchKernelGGL((k_route_scatter<uint32_t>), grid, 256, 0, c->stream, (const uint32_t *)d_keys, n_keys, n_shards, n_waves, c->d_route_off,
+                           (uint32_t *)d_send_keys, d_send_src);
+    else
+        hipLaunchKernelGGL((k_route_scatter<unsigned long long>), grid, 256, 0, c->stream, (const unsigned long long *)d_keys, n_keys, n_shards, n_waves,
+                           c->d_route_off, (unsigned long long *)d_send_keys, d_send_src);
+    HIPCHK(c, hipGetLastError());
+    // per-shard totals = differences of the shard start offsets
+    uint32_t starts[65];
+    for (uint32_t s = 0; s <= n_shards; s++)
+        HIPCHK(c, hipMemcpyAsync(&starts[s], c->d_route_off + (uint64_t)s * n_waves, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = starts[s + 1] - starts[s];
+    return NKML_OK;
+}
+
+int nkml_unroute_flags_device(nkml_ctx *c, const uint8_t *d_recv_flags, const uint32_t *d_send_src, uint64_t n_sent, uint8_t *d_flags,
+                              uint64_t n_keys)
+{
+    if (!c || !d_flags || (n_sent && (!d_recv_flags || !d_send_src))) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemsetAsync(d_flags, 0, n_keys, c->stream));
+    if (n_sent) {
+        hipLaunchKernelGGL(k_unroute_flags, GRID_PERSIST, 256, 0, c->stream, d_recv_flags, d_send_src, n_sent, d_flags);
+        HIPCHK(c, hipGetLastError());
+    }
     return NKML_OK;
 }
 

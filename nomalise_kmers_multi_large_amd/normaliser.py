@@ -181,6 +181,14 @@ class KmerNormaliser:
     def reduce_reads_device(self, d_keys, d_flags, d_offsets, n_reads, d_high, d_total):
         self._chk(self.lib.nkml_reduce_reads_device(self.h, d_keys, d_flags, d_offsets, n_reads, d_high, d_total))
 
+    def route_keys_device(self, d_keys, n_keys, n_shards, d_send_keys, d_send_src):
+        counts = (ctypes.c_uint64 * n_shards)()
+        self._chk(self.lib.nkml_route_keys_device(self.h, d_keys, n_keys, n_shards, d_send_keys, d_send_src, counts))
+        return [int(x) for x in counts]
+
+    def unroute_flags_device(self, d_recv_flags, d_send_src, n_sent, d_flags, n_keys):
+        self._chk(self.lib.nkml_unroute_flags_device(self.h, d_recv_flags, d_send_src, n_sent, d_flags, n_keys))
+
     def dump_table(self, max_entries=1 << 24):
         codes = np.zeros(max_entries, dtype=np.uint64)
         counts = np.zeros(max_entries, dtype=np.uint32)

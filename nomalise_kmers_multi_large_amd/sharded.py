@@ -1,0 +1,163 @@
+"""K-mer-sharded normaliser over several GPUs of one node: one process per GPU, torch.distributed (RCCL) for
+the exchange, the HIP library for everything else.
+
+The reference has nothing like this (its threads keep private tables and never merge them,
+normalise_kmers_multi_large.c:2421); read-sharding with private tables would change the results, so the table
+is sharded by k-mer instead and results stay identical to the single-stream run:
+
+  global stream order of one step = rank 0's reads, then rank 1's, ... (each rank brings a contiguous slice)
+  1. every rank k-merises its reads (keys in stream order)
+  2. keys are stably partitioned by owning rank and exchanged with one all-to-all; what an owner receives is
+     ordered by source rank, and within a source by stream position, i.e. it is the global stream order
+     restricted to the keys this rank owns - exactly what the counting pass needs for exact ranks
+  3. the owner counts them against its shard of the table (same kernels as on one GPU) and gets one flag per key
+  4. the flags travel back with the reverse all-to-all and are put back at their base positions
+  5. per-read counters are reduced where the reads live and gathered on rank 0, which takes the keep/skip
+     decisions for the whole step (ordered write-back happens there)
+
+The engine object does the device work; `HipShardEngine` is the product one.  Tests drive the same exchange
+logic over gloo with a CPU checker engine.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HipShardEngine:
+    """Stage-by-stage face of the HIP library on one GPU, holding torch tensors for the buffers."""
+
+    def __init__(self, ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False, slack=1.5):
+        from .normaliser import KmerNormaliser
+        self.dev = torch.device("cuda", device)
+        self.cap = int(max_bases * slack) // 16 * 16 + 64
+        self.nk = KmerNormaliser(ksize, depth, coverage, canonical, device=device, max_batch_reads=max_reads,
+                                 max_batch_bases=self.cap, profile=profile)
+        self.nk.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.key_dtype = torch.int32 if self.nk.key_bytes == 4 else torch.int64
+        npos = (max_bases + 15) // 16 * 16
+        self.keys = torch.zeros(npos, dtype=self.key_dtype, device=self.dev)
+        self.send_keys = torch.zeros(npos, dtype=self.key_dtype, device=self.dev)
+        self.send_src = torch.zeros(npos, dtype=torch.int32, device=self.dev)
+        self.flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
+        self.recv_keys = torch.zeros(self.cap, dtype=self.key_dtype, device=self.dev)
+        self.recv_flags = torch.zeros(self.cap, dtype=torch.uint8, device=self.dev)
+        self.back_flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
+        self.high = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
+        self.total = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
+
+    def kmerise(self, seq, offsets, n_reads, n_bases):
+        self.nk.kmerise_device(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, self.keys.data_ptr())
+        return self.keys[: (n_bases + 15) // 16 * 16]
+
+    def route(self, keys, n_shards):
+        counts = self.nk.route_keys_device(keys.data_ptr(), keys.numel(), n_shards, self.send_keys.data_ptr(), self.send_src.data_ptr())
+        n = sum(counts)
+        return self.send_keys[:n], self.send_src[:n], counts
+
+    def recv_buffer(self, n):
+        if n > self.cap:
+            raise RuntimeError("received %d keys, more than the %d this rank was sized for" % (n, self.cap))
+        return self.recv_keys[:n]
+
+    def count(self, recv_keys):
+        n = recv_keys.numel()
+        n16 = (n + 15) // 16 * 16
+        if n16 > n:
+            self.recv_keys[n:n16].zero_()
+        self.nk.count_keys_device(self.recv_keys.data_ptr(), n16, self.recv_flags.data_ptr())
+        return self.recv_flags[:n]
+
+    def back_buffer(self, n):
+        return self.back_flags[:n]
+
+    def unroute(self, back_flags, send_src, n_positions):
+        self.nk.unroute_flags_device(back_flags.data_ptr(), send_src.data_ptr(), back_flags.numel(), self.flags.data_ptr(), n_positions)
+        return self.flags[:n_positions]
+
+    def reduce(self, flags, offsets, n_reads):
+        self.nk.reduce_reads_device(self.keys.data_ptr(), flags.data_ptr(), offsets.data_ptr(), n_reads, self.high.data_ptr(), self.total.data_ptr())
+        return self.high[:n_reads], self.total[:n_reads]
+
+    def decide(self, high, total, n_units, paired, keep):
+        self.nk.decide_device(high.data_ptr(), total.data_ptr(), n_units, paired, keep.data_ptr())
+
+    def synchronize(self):
+        self.nk.synchronize()
+
+    def reset(self):
+        self.nk.reset()
+
+    def stats(self):
+        return self.nk.stats()
+
+
+class ShardedNormaliser:
+    """One step = every rank's batch of reads, processed as one global batch (rank-major stream order)."""
+
+    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False):
+        self.eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.gather_to_root = gather_to_root
+        # rehearsal aid only: lets several ranks share one GPU under the gloo backend (RCCL refuses two ranks on
+        # one device) by bouncing the exchanged buffers through host memory
+        self.stage_through_host = stage_through_host
+
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        if not self.stage_through_host or not inp.is_cuda:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+            return
+        self.eng.synchronize()
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, inp.cpu(), out_splits, in_splits, group=self.group)
+        out.copy_(h_out)
+
+    def _p2p_gather(self, packed, sizes):
+        host = self.stage_through_host and packed.is_cuda
+        src = packed.cpu() if host else packed.contiguous()
+        if self.rank != 0:
+            dist.send(src, dst=0, group=self.group)
+            return None
+        bufs = [torch.empty((2, s), dtype=src.dtype, device=src.device) for s in sizes]
+        bufs[0].copy_(src)
+        for q in [dist.irecv(bufs[r], src=r, group=self.group) for r in range(1, self.world)]:
+            q.wait()
+        return [b.to(packed.device) for b in bufs] if host else bufs
+
+    def _exchange_counts(self, send_counts, like):
+        sc = torch.tensor(send_counts, dtype=torch.int64, device="cpu" if self.stage_through_host else like.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)
+        return [int(x) for x in rc.tolist()]
+
+    def process_step(self, seq, offsets, n_reads, n_bases):
+        """seq/offsets: this rank's reads (device tensors for the HIP engine).  Returns (high, total) of this
+        rank's reads, and on rank 0 additionally the gathered (high_all, total_all) lists per rank."""
+        eng, W = self.eng, self.world
+        keys = eng.kmerise(seq, offsets, n_reads, n_bases)
+        send_keys, send_src, send_counts = eng.route(keys, W)
+        recv_counts = self._exchange_counts(send_counts, send_keys)
+        recv_keys = eng.recv_buffer(sum(recv_counts))
+        self._all_to_all(recv_keys, send_keys, recv_counts, send_counts)
+        recv_flags = eng.count(recv_keys)
+        back = eng.back_buffer(sum(send_counts))
+        self._all_to_all(back, recv_flags, send_counts, recv_counts)
+        flags = eng.unroute(back, send_src, keys.numel())
+        high, total = eng.reduce(flags, offsets, n_reads)
+        gathered = None
+        if self.gather_to_root:
+            cdev = "cpu" if self.stage_through_host else high.device
+            n_all = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(W)]
+            dist.all_gather(n_all, torch.tensor([n_reads], dtype=torch.int64, device=cdev), group=self.group)
+            gathered = self._p2p_gather(torch.stack([high, total]), [int(x.item()) for x in n_all])
+        return high, total, gathered
+
+    def synchronize(self):
+        self.eng.synchronize()
+
+    def reset(self):
+        self.eng.reset()
+
+    def stats(self):
+        return self.eng.stats()

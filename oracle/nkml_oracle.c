@@ -314,6 +314,51 @@ static void window_loop(nkml_oracle *o, const char *seq, int len, int do_init, i
     }
 }
 
+int nkml_oracle_keys(int k, int canonical, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads, uint64_t *keys)
+{
+    const uint64_t mask = pow4(k) - 1;
+    const int rc_shift = 2 * (k - 1);
+    for (uint32_t r = 0; r < n_reads; r++) {
+        uint64_t a = offsets[r], b = offsets[r + 1];
+        uint64_t fwd = 0, rc = 0;
+        for (uint64_t p = a; p < b; p++) {
+            if (!base_ok(seq[p]))
+                return -1;
+            keys[p] = 0;
+            uint64_t c = (uint64_t)base_code(seq[p]);
+            fwd = ((fwd << 2) | c) & mask;
+            rc = (rc >> 2) | ((3 - c) << rc_shift);
+            if (p + 1 < a + (uint64_t)k)
+                continue;
+            keys[p + 1 - (uint64_t)k] = (canonical && rc < fwd) ? rc : fwd;
+        }
+    }
+    return 0;
+}
+
+void nkml_oracle_count_keys(nkml_oracle *o, const uint64_t *keys, uint64_t n, uint8_t *flags)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        flags[i] = 0;
+        if (!keys[i])
+            continue;
+        int32_t *c = exact_slot(o, keys[i]);
+        uint32_t cnt;
+        if (o->direct) {
+            uint32_t v = (uint32_t)*c;
+            if (v == 0)
+                o->used++;
+            cnt = (v & 0x7fffffffu) + 1;
+            *c = (int32_t)(cnt | 0x80000000u);
+        } else {
+            slot_t *s = (slot_t *)((char *)c - offsetof(slot_t, count));
+            if (!s->pad) { s->pad = 1; o->used++; }
+            cnt = (uint32_t)++(*c);
+        }
+        flags[i] = ((int64_t)cnt >= o->depth) ? 1 : 2;
+    }
+}
+
 static int validate(const char *seq, int len)
 {
     for (int i = 0; i < len; i++)

@@ -68,6 +68,9 @@ class Oracle:
             lib.nkml_oracle_pair.argtypes = [vp, cp, ci, cp, ci, ip, ip, ip, ip]
             lib.nkml_oracle_seed_read.argtypes = [vp, cp, ci]
             lib.nkml_oracle_batch.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp]
+            lib.nkml_oracle_keys.argtypes = [ci, ci, vp, vp, ctypes.c_uint32, vp]
+            lib.nkml_oracle_count_keys.argtypes = [vp, vp, ctypes.c_uint64, vp]
+            lib.nkml_oracle_count_keys.restype = None
             lib.nkml_oracle_unique.restype = ctypes.c_uint64
             lib.nkml_oracle_unique.argtypes = [vp]
             lib.nkml_oracle_count_of.restype = ctypes.c_uint32
@@ -120,6 +123,22 @@ class Oracle:
         if rc != 0:
             raise ValueError("invalid base in batch")
         return high, total
+
+    @classmethod
+    def keys(cls, k, canonical, seq, offsets):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        keys = np.zeros(len(seq), dtype=np.uint64)
+        rc = cls.lib().nkml_oracle_keys(k, int(bool(canonical)), seq.ctypes.data, offsets.ctypes.data, len(offsets) - 1, keys.ctypes.data)
+        if rc != 0:
+            raise ValueError("invalid base")
+        return keys
+
+    def count_keys(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        flags = np.zeros(len(keys), dtype=np.uint8)
+        self.lib().nkml_oracle_count_keys(self.h, keys.ctypes.data, len(keys), flags.ctypes.data)
+        return flags
 
     @property
     def unique(self):

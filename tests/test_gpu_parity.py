@@ -216,3 +216,55 @@ def test_table_dump_matches_oracle_counts(nk, oracle_lib):
             codes, counts, n = g.dump_table()
             assert n == o.unique == len(codes)
             assert all(o.count_of(int(c)) == int(v) for c, v in zip(codes[:5000], counts[:5000]))
+
+
+def test_sharded_stages_on_one_gpu(nk, oracle_lib):
+    """The device stages of the k-mer-sharded path (k-merise, stable routing by owner, count at the owner, flags
+    back to their positions, per-read reduce) with three shards emulated in one process on one GPU: the
+    all-to-all is replaced by slicing, everything else is the product code.  Equals the single-stream oracle."""
+    import torch
+    from nomalise_kmers_multi_large_amd.sharded import HipShardEngine
+    W = 3
+    for k, depth, canonical in ((13, 3, True), (23, 2, False)):
+        engines = [HipShardEngine(k, depth, 0.9, canonical, 0, max_reads=4096, max_bases=1 << 18, slack=3.0) for _ in range(W)]
+        o = oracle_lib(k, depth, canonical)
+        rng = np.random.default_rng(77 + k)
+        for step in range(3):
+            per_rank = [random_reads(rng, 300 + 50 * r, k, 120, b"ACG") for r in range(W)]
+            routed = []
+            for r in range(W):
+                seq, off = engines[r].nk._concat(per_rank[r])
+                d_seq = torch.from_numpy(seq.copy()).cuda()
+                d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+                keys = engines[r].kmerise(d_seq, d_off, len(per_rank[r]), len(seq))
+                sk, ss, counts = engines[r].route(keys, W)
+                assert sum(counts) == int((keys != 0).sum())
+                routed.append((d_off, keys.numel(), sk.clone(), ss.clone(), counts))
+            back = [[None] * W for _ in range(W)]
+            for owner in range(W):          # "all-to-all": owner receives, in source order, each source's slice
+                parts = []
+                for src in range(W):
+                    c = routed[src][4]
+                    a = sum(c[:owner])
+                    parts.append(routed[src][2][a:a + c[owner]])
+                recv = engines[owner].recv_buffer(sum(p.numel() for p in parts))
+                recv.copy_(torch.cat(parts))
+                fl = engines[owner].count(recv).clone()
+                a = 0
+                for src in range(W):
+                    n = parts[src].numel()
+                    back[src][owner] = fl[a:a + n]
+                    a += n
+            for r in range(W):
+                d_off, npos, sk, ss, counts = routed[r]
+                bf = engines[r].back_buffer(sum(counts))
+                bf.copy_(torch.cat(back[r]))
+                flags = engines[r].unroute(bf, ss, npos)
+                high, total = engines[r].reduce(flags, d_off, len(per_rank[r]))
+                engines[r].synchronize()
+                want = [o.read(x) for x in per_rank[r]]
+                np.testing.assert_array_equal(high.cpu().numpy(), [w[1] for w in want])
+                np.testing.assert_array_equal(total.cpu().numpy(), [w[2] for w in want])
+        assert sum(e.stats()["unique_kmers"] for e in engines) == o.unique
+        for e in engines:
+            e.nk.close()

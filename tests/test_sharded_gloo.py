@@ -1,0 +1,143 @@
+"""The key exchange of the k-mer-sharded path, run for real over torch.distributed (gloo, CPU, 2 and 3 ranks).
+The device work is done by a CPU checker engine built on the oracle, so what is under test is the exchange
+logic itself: ownership, stable routing, split sizes, the flags' way back, the gather on rank 0.  The result
+must equal one oracle reading the global stream (rank 0's reads, then rank 1's, ...) on a single table."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import Oracle
+
+OWNER_MUL = np.uint64(0x9E3779B97F4A7C15)
+
+
+def owner_np(keys, n_shards):
+    return ((keys * OWNER_MUL) >> np.uint64(32)) % np.uint64(n_shards)
+
+
+class CheckerEngine:
+    """Same stage interface as HipShardEngine, on CPU tensors, with the oracle as the table."""
+
+    def __init__(self, k, depth, canonical):
+        self.k, self.canonical = k, canonical
+        self.o = Oracle(k, depth, canonical)
+
+    def kmerise(self, seq, offsets, n_reads, n_bases):
+        keys = Oracle.keys(self.k, self.canonical, seq.numpy(), offsets.numpy().astype(np.uint64))
+        return torch.from_numpy(keys.view(np.int64))
+
+    def route(self, keys, n_shards):
+        k = keys.numpy().view(np.uint64)
+        nz = np.nonzero(k)[0]
+        own = owner_np(k[nz], n_shards).astype(np.int64)
+        order = np.argsort(own, kind="stable")
+        counts = [int((own == s).sum()) for s in range(n_shards)]
+        return torch.from_numpy(k[nz][order].view(np.int64).copy()), torch.from_numpy(nz[order].astype(np.int32)), counts
+
+    def recv_buffer(self, n):
+        return torch.empty(n, dtype=torch.int64)
+
+    def count(self, recv_keys):
+        return torch.from_numpy(self.o.count_keys(recv_keys.numpy().view(np.uint64)))
+
+    def back_buffer(self, n):
+        return torch.empty(n, dtype=torch.uint8)
+
+    def unroute(self, back_flags, send_src, n_positions):
+        flags = np.zeros(n_positions, dtype=np.uint8)
+        flags[send_src.numpy()] = back_flags.numpy()
+        return torch.from_numpy(flags)
+
+    def reduce(self, flags, offsets, n_reads):
+        f = flags.numpy()
+        off = offsets.numpy()
+        high = np.array([(f[off[i]:off[i + 1]] == 1).sum() for i in range(n_reads)], dtype=np.int32)
+        total = np.array([(f[off[i]:off[i + 1]] != 0).sum() for i in range(n_reads)], dtype=np.int32)
+        return torch.from_numpy(high), torch.from_numpy(total)
+
+    def synchronize(self):
+        pass
+
+    def stats(self):
+        return {"unique_kmers": self.o.unique}
+
+
+def make_reads(seed, n, lo, hi, alphabet=b"ACG"):
+    rng = np.random.default_rng(seed)
+    al = np.frombuffer(alphabet, dtype=np.uint8)
+    return [al[rng.integers(0, len(al), rng.integers(lo, hi + 1))].tobytes() for _ in range(n)]
+
+
+def concat(reads):
+    off = np.zeros(len(reads) + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    return np.frombuffer(b"".join(reads), dtype=np.uint8).copy(), off
+
+
+def worker(rank, world, port, k, depth, canonical, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
+        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical))
+        out = []
+        for step in range(steps):
+            reads = make_reads(100 * step + rank, 40 + 7 * rank, k, 90)   # ragged: ranks bring different amounts
+            seq, off = concat(reads)
+            high, total, gathered = sn.process_step(torch.from_numpy(seq), torch.from_numpy(off), len(reads), len(seq))
+            if rank == 0:
+                out.append([g.numpy().copy() for g in gathered])
+        uniq = torch.tensor([sn.stats()["unique_kmers"]], dtype=torch.int64)
+        dist.all_reduce(uniq)
+        if rank == 0:
+            q.put((out, int(uniq.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,k,depth,canonical", [(2, 9, 3, False), (2, 21, 2, True), (3, 11, 4, True)])
+def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical):
+    steps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, uniq = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single stream, single table
+    o = oracle_lib(k, depth, canonical)
+    for step in range(steps):
+        for rank in range(world):
+            reads = make_reads(100 * step + rank, 40 + 7 * rank, k, 90)
+            want = [o.read(r) for r in reads]
+            np.testing.assert_array_equal(got[step][rank][0], [w[1] for w in want])
+            np.testing.assert_array_equal(got[step][rank][1], [w[2] for w in want])
+    assert uniq == o.unique   # shards are disjoint: their sizes add up to the single table's
+
+
+def test_owner_rule_matches_library():
+    from nomalise_kmers_multi_large_amd import binding
+    lib = binding.load_library()
+    rng = np.random.default_rng(0)
+    keys = rng.integers(1, 1 << 62, 2000, dtype=np.uint64)
+    for n in (1, 2, 3, 8):
+        want = owner_np(keys, n)
+        assert [lib.nkml_owner_of(int(x), n) for x in keys] == want.tolist()
