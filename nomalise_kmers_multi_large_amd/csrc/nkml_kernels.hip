@@ -140,13 +140,13 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, u
 // (get_canonical_kmer, normalise_kmers_multi_large.c:1175-1180).  Writes 0 where no window of a single read
 // starts, or where the code is 0 (skipped by the reference, :1483-1484).
 // ------------------------------------------------------------------------------------------------------
+// The 16 keys of packed word w.  Every lane of the wavefront must call it (shuffles); lanes with live == false
+// get zeros.  Consecutive lanes must hold consecutive words.
 template <typename KEY, bool CANON>
-__global__ void __launch_bounds__(256) k_kmerise(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
-                                                 uint64_t n_bases, uint64_t n_words, int k, KEY *__restrict__ keys)
+__device__ __forceinline__ void word_keys(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits, uint64_t w,
+                                          bool live, uint64_t n_bases, int k, KEY (&out)[16])
 {
-    uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     int lane = threadIdx.x & 63;
-    bool live = w < n_words;
     uint32_t w0 = live ? packed[w] : 0u;         // packed/startbits carry 4 zero words of halo
     uint32_t s0 = live ? startbits[w] : 0u;
     uint32_t w1 = __shfl_down(w0, 1), w2 = __shfl_down(w0, 2);
@@ -155,7 +155,11 @@ __global__ void __launch_bounds__(256) k_kmerise(const uint32_t *__restrict__ pa
         if (lane == 63) { w1 = packed[w + 1]; s1 = startbits[w + 1]; }
         w2 = packed[w + 2]; s2 = startbits[w + 2];
     }
-    if (!live) return;
+    if (!live) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) out[j] = (KEY)0;
+        return;
+    }
 
     const uint64_t S = (uint64_t)s0 | ((uint64_t)s1 << 16) | ((uint64_t)s2 << 32);
     const uint64_t span = (1ull << (k - 1)) - 1;             // positions 1..k-1 after the window start
@@ -171,7 +175,6 @@ __global__ void __launch_bounds__(256) k_kmerise(const uint32_t *__restrict__ pa
         rc = r;
     }
     const uint64_t rem = n_bases - w * 16; // bases from this word's first position to the end of the batch
-    KEY out[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         if (j > 0) {
@@ -185,6 +188,17 @@ __global__ void __launch_bounds__(256) k_kmerise(const uint32_t *__restrict__ pa
         if (CANON) code = rc < fwd ? rc : fwd;
         out[j] = valid ? (KEY)code : (KEY)0;
     }
+}
+
+template <typename KEY, bool CANON>
+__global__ void __launch_bounds__(256) k_kmerise(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
+                                                 uint64_t n_bases, uint64_t n_words, int k, KEY *__restrict__ keys)
+{
+    uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool live = w < n_words;
+    KEY out[16];
+    word_keys<KEY, CANON>(packed, startbits, w, live, n_bases, k, out);
+    if (!live) return;
     KEY *dst = keys + w * 16;
     if (sizeof(KEY) == 4) {
         uint4 *d4 = reinterpret_cast<uint4 *>(dst);
@@ -335,7 +349,7 @@ __global__ void __launch_bounds__(256) k_seed_direct(const uint32_t *__restrict_
 // (id << posbits) | position-in-batch.  The filter screens, the count (>= depth, and the occurrence was not
 // saturated when the pass began) confirms, so the list is exact.  Nothing runs if no k-mer crossed.
 // Hits are staged in LDS and flushed whenever another full iteration might not fit.
-constexpr int OCC_CAP = 3072;
+constexpr int OCC_CAP = 6144; // 48 KB of LDS: room for one more full iteration (256 lanes x 16 windows) past the flush threshold
 using OccList = BlockList<unsigned long long, OCC_CAP>;
 
 __global__ void __launch_bounds__(256) k_collect_direct(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ flags,
@@ -457,7 +471,7 @@ __device__ __forceinline__ uint64_t find_or_insert(Slot *__restrict__ slots, uin
 }
 
 __global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *__restrict__ keys, uint64_t n, uint8_t *__restrict__ flags,
-                                                      unsigned long long *__restrict__ slot_of, Slot *__restrict__ slots,
+                                                      Slot *__restrict__ slots,
                                                       uint64_t cap_mask, uint32_t *__restrict__ filter, uint32_t depth,
                                                       int count_saturated, Counters *ctr,
                                                       unsigned long long *__restrict__ list_sat,
@@ -484,12 +498,11 @@ __global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *
                     if (count_saturated) atomicAdd(&slots[h].state, 1u); // slot.count stays frozen for the ranking pass
                 } else {
                     fl = FLAG_LOW;
-                    slot_of[i] = h;
                     uint32_t c1 = atomicAdd(&slots[h].count, 1u) + 1;
                     if (c1 == depth - 1) blocklist_push(bl_sat, (unsigned long long)h, list_sat, &ctr->n_sat_new);
                     if (c1 == depth) {
                         blocklist_push(bl_cross, (unsigned long long)h, list_cross, &ctr->n_cross);
-                        filter_set(filter, filter_index((unsigned long long)h));
+                        filter_set(filter, filter_index(key));
                     }
                 }
             }
@@ -517,9 +530,22 @@ __global__ void __launch_bounds__(256) k_seed_hashed(const unsigned long long *_
     flush_tallies(uniq, 0, 0, ctr);
 }
 
-__global__ void __launch_bounds__(256) k_collect_hashed(const uint8_t *__restrict__ flags, const unsigned long long *__restrict__ slot_of,
+// read-only lookup: slot of a key that is known to be stored, ~0 if it is not
+__device__ __forceinline__ uint64_t find_slot(const Slot *__restrict__ slots, uint64_t cap_mask, unsigned long long key)
+{
+    uint64_t h = mix64(key) & cap_mask;
+    for (uint64_t probes = 0; probes <= cap_mask; probes++) {
+        unsigned long long cur = slots[h].key;
+        if (cur == key) return h;
+        if (cur == 0) return ~0ull;
+        h = (h + 1) & cap_mask;
+    }
+    return ~0ull;
+}
+
+__global__ void __launch_bounds__(256) k_collect_hashed(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ flags,
                                                         uint64_t n, uint64_t pos_base, const uint32_t *__restrict__ filter,
-                                                        const Slot *__restrict__ slots, uint32_t depth, int posbits,
+                                                        const Slot *__restrict__ slots, uint64_t cap_mask, uint32_t depth, int posbits,
                                                         unsigned long long *__restrict__ occ, Counters *ctr)
 {
     __shared__ OccList bl;
@@ -530,9 +556,11 @@ __global__ void __launch_bounds__(256) k_collect_hashed(const uint8_t *__restric
     uint64_t nr = (n + stride - 1) / stride * stride;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nr; i += stride) {
         if (i < n && flags[i] == FLAG_LOW) {
-            unsigned long long h = slot_of[i];
-            if (filter_test(filter, filter_index(h)) && slots[h].count >= depth)
-                blocklist_push(bl, (h << posbits) | (pos_base + i), occ, &ctr->n_occ);
+            unsigned long long key = keys[i];
+            if (filter_test(filter, filter_index(key))) {
+                uint64_t h = find_slot(slots, cap_mask, key);
+                if (h != ~0ull && slots[h].count >= depth) blocklist_push(bl, (unsigned long long)(h << posbits) | (pos_base + i), occ, &ctr->n_occ);
+            }
         }
         __syncthreads();
         uint32_t fill = bl.n;
@@ -550,6 +578,249 @@ __global__ void __launch_bounds__(256) k_apply_hashed(const unsigned long long *
     uint32_t stride = gridDim.x * 256;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_sat; i += stride) atomicOr(&slots[list_sat[i]].state, ST_SAT);
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_cross; i += stride) atomicOr(&slots[list_cross[i]].state, ST_SAT);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fused single-GPU form of K2+K3 (+K4a): the keys of a packed word are made in registers and counted at once,
+// so the per-position key and flag arrays never exist.  Per packed word one 32-bit result: bit j = window j is
+// HIGH, bit 16+j = window j was counted below depth in its pass (LOW).  One lane = one word = up to 16
+// occurrences, whose bitmap gathers and atomic adds are all independent.
+// ------------------------------------------------------------------------------------------------------
+template <bool CANON>
+__global__ void __launch_bounds__(256) k_count_words_direct(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
+                                                            uint64_t n_bases, uint64_t w_begin, uint64_t w_end, int k,
+                                                            uint32_t *__restrict__ wflags, uint32_t *__restrict__ counts,
+                                                            const uint32_t *__restrict__ sat, uint32_t *__restrict__ filter, uint32_t depth,
+                                                            uint32_t *__restrict__ extra, Counters *ctr, uint32_t *__restrict__ list_sat,
+                                                            uint32_t *__restrict__ list_cross)
+{
+    __shared__ BlockList<uint32_t, 1024> bl_sat, bl_cross;
+    if (threadIdx.x == 0) { bl_sat.n = 0; bl_cross.n = 0; }
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256, n = w_end - w_begin, n_words_total = (n_bases + 15) / 16;
+    const uint64_t nr = (n + stride - 1) / stride * stride; // whole wavefronts iterate together (shuffles inside)
+    uint32_t uniq = 0, counted = 0, nsat = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nr; i += stride) {
+        const bool live = i < n;
+        const uint64_t w = w_begin + i;
+        uint32_t key[16], sw[16], old[16];
+        word_keys<uint32_t, CANON>(packed, startbits, w, w < n_words_total, n_bases, k, key);
+        if (!live) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) key[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) sw[j] = key[j] ? sat[key[j] >> 5] : 0u;
+        uint32_t hi = 0, lo = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            old[j] = 0;
+            if (key[j]) {
+                counted++;
+                if ((sw[j] >> (key[j] & 31)) & 1u) {
+                    hi |= 1u << j;
+                    nsat++;
+                    if (extra) atomicAdd(&extra[key[j]], 1u);
+                } else {
+                    lo |= 1u << j;
+                    old[j] = atomicAdd(&counts[key[j]], 1u);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if ((lo >> j) & 1u) {
+                uint32_t c1 = (old[j] & COUNT_MASK) + 1;
+                if (old[j] == 0) uniq++;
+                if (c1 == depth - 1) blocklist_push(bl_sat, key[j], list_sat, &ctr->n_sat_new);
+                if (c1 == depth) {
+                    blocklist_push(bl_cross, key[j], list_cross, &ctr->n_cross);
+                    filter_set(filter, filter_index(key[j]));
+                }
+            }
+        }
+        if (live) wflags[w] = hi | (lo << 16);
+    }
+    blocklist_flush(bl_sat, list_sat, &ctr->n_sat_new);
+    blocklist_flush(bl_cross, list_cross, &ctr->n_cross);
+    flush_tallies(uniq, counted, nsat, ctr);
+}
+
+template <bool CANON>
+__global__ void __launch_bounds__(256) k_count_words_hashed(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
+                                                            uint64_t n_bases, uint64_t w_begin, uint64_t w_end, int k,
+                                                            uint32_t *__restrict__ wflags, Slot *__restrict__ slots, uint64_t cap_mask,
+                                                            uint32_t *__restrict__ filter, uint32_t depth, int count_saturated, Counters *ctr,
+                                                            unsigned long long *__restrict__ list_sat,
+                                                            unsigned long long *__restrict__ list_cross)
+{
+    __shared__ BlockList<unsigned long long, 512> bl_sat, bl_cross;
+    if (threadIdx.x == 0) { bl_sat.n = 0; bl_cross.n = 0; }
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256, n = w_end - w_begin, n_words_total = (n_bases + 15) / 16;
+    const uint64_t nr = (n + stride - 1) / stride * stride;
+    uint32_t uniq = 0, counted = 0, nsat = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nr; i += stride) {
+        const bool live = i < n;
+        const uint64_t w = w_begin + i;
+        unsigned long long key[16];
+        word_keys<unsigned long long, CANON>(packed, startbits, w, w < n_words_total, n_bases, k, key);
+        if (!live) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) key[j] = 0;
+        }
+        uint32_t hi = 0, lo = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (!key[j]) continue;
+            counted++;
+            bool inserted; uint32_t state;
+            uint64_t h = find_or_insert(slots, cap_mask, key[j], inserted, state);
+            if (h == ~0ull) { atomicAdd(&ctr->probe_overflow, 1u); continue; }
+            if (inserted) uniq++;
+            if (state & ST_SAT) {
+                hi |= 1u << j;
+                nsat++;
+                if (count_saturated) atomicAdd(&slots[h].state, 1u);
+            } else {
+                lo |= 1u << j;
+                uint32_t c1 = atomicAdd(&slots[h].count, 1u) + 1;
+                if (c1 == depth - 1) blocklist_push(bl_sat, (unsigned long long)h, list_sat, &ctr->n_sat_new);
+                if (c1 == depth) {
+                    blocklist_push(bl_cross, (unsigned long long)h, list_cross, &ctr->n_cross);
+                    filter_set(filter, filter_index(key[j]));
+                }
+            }
+        }
+        if (live) wflags[w] = hi | (lo << 16);
+    }
+    blocklist_flush(bl_sat, list_sat, &ctr->n_sat_new);
+    blocklist_flush(bl_cross, list_cross, &ctr->n_cross);
+    flush_tallies(uniq, counted, nsat, ctr);
+}
+
+// seeding form (sequence_to_hash_zero): keys become present, counts are left alone
+template <bool CANON, bool DIRECT>
+__global__ void __launch_bounds__(256) k_seed_words(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
+                                                    uint64_t n_bases, uint64_t n_words, int k, uint32_t *__restrict__ counts,
+                                                    Slot *__restrict__ slots, uint64_t cap_mask, Counters *ctr)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    const uint64_t nr = (n_words + stride - 1) / stride * stride;
+    uint32_t uniq = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nr; w += stride) {
+        const bool live = w < n_words;
+        if (DIRECT) {
+            uint32_t key[16];
+            word_keys<uint32_t, CANON>(packed, startbits, w, live, n_bases, k, key);
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+                if (key[j] && atomicOr(&counts[key[j]], SEEDED_BIT) == 0) uniq++;
+        } else {
+            unsigned long long key[16];
+            word_keys<unsigned long long, CANON>(packed, startbits, w, live, n_bases, k, key);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (!key[j]) continue;
+                bool inserted; uint32_t state;
+                uint64_t h = find_or_insert(slots, cap_mask, key[j], inserted, state);
+                if (h == ~0ull) atomicAdd(&ctr->probe_overflow, 1u);
+                else if (inserted) uniq++;
+            }
+        }
+    }
+    flush_tallies(uniq, 0, 0, ctr);
+}
+
+// K4a on word flags: occurrences marked LOW whose k-mer crossed in this pass -> (id << posbits) | position.
+template <bool CANON, bool DIRECT>
+__global__ void __launch_bounds__(256) k_collect_words(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
+                                                       uint64_t n_bases, uint64_t w_begin, uint64_t w_end, int k,
+                                                       const uint32_t *__restrict__ wflags, const uint32_t *__restrict__ filter,
+                                                       const uint32_t *__restrict__ counts, const Slot *__restrict__ slots, uint64_t cap_mask,
+                                                       uint32_t depth, int posbits, unsigned long long *__restrict__ occ, Counters *ctr)
+{
+    __shared__ OccList bl;
+    if (ctr->n_cross == 0) return; // uniform: written by the previous kernel
+    if (threadIdx.x == 0) bl.n = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * 256, n = w_end - w_begin, n_words_total = (n_bases + 15) / 16;
+    const uint64_t nr = (n + stride - 1) / stride * stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nr; i += stride) {
+        const bool live = i < n;
+        const uint64_t w = w_begin + i;
+        const uint32_t lo = live ? (wflags[w] >> 16) : 0u;
+        if (__any(lo != 0)) { // the whole wavefront takes part in the shuffles of word_keys
+            if (DIRECT) {
+                uint32_t key[16];
+                word_keys<uint32_t, CANON>(packed, startbits, w, w < n_words_total, n_bases, k, key);
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (((lo >> j) & 1u) && filter_test(filter, filter_index(key[j])) && (counts[key[j]] & COUNT_MASK) >= depth)
+                        blocklist_push(bl, ((unsigned long long)key[j] << posbits) | (w * 16 + j), occ, &ctr->n_occ);
+            } else {
+                unsigned long long key[16];
+                word_keys<unsigned long long, CANON>(packed, startbits, w, w < n_words_total, n_bases, k, key);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (((lo >> j) & 1u) && filter_test(filter, filter_index(key[j]))) {
+                        uint64_t h = find_slot(slots, cap_mask, key[j]);
+                        if (h != ~0ull && slots[h].count >= depth)
+                            blocklist_push(bl, (unsigned long long)(h << posbits) | (w * 16 + j), occ, &ctr->n_occ);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t fill = bl.n;
+        __syncthreads(); // every lane has read the same fill level before anyone pushes again
+        if (fill > OCC_CAP - 4096) blocklist_flush(bl, occ, &ctr->n_occ);
+    }
+    blocklist_flush(bl, occ, &ctr->n_occ);
+}
+
+// K4b for word flags: same ranking as k_rank, the HIGH bit of the occurrence's word is set with an atomic OR
+template <typename TABLE>
+__global__ void __launch_bounds__(256) k_rank_words(const unsigned long long *__restrict__ occ, uint32_t n_occ, int posbits, TABLE table,
+                                                    uint32_t depth, uint32_t *__restrict__ wflags)
+{
+    uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_occ) return;
+    unsigned long long e = occ[s];
+    unsigned long long id = e >> posbits;
+    unsigned long long lo_key = id << posbits, hi_key = (id + 1) << posbits;
+    uint32_t lo = 0, hi = s;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (occ[mid] < lo_key) lo = mid + 1; else hi = mid; }
+    uint32_t start = lo;
+    lo = s + 1; hi = n_occ;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (occ[mid] < hi_key) lo = mid + 1; else hi = mid; }
+    uint32_t m = lo - start, i = s - start;
+    uint32_t F = table.count_of(id);
+    if (F - m + i + 1 >= depth) {
+        unsigned long long pos = e & ((1ull << posbits) - 1);
+        atomicOr(&wflags[pos >> 4], 1u << (pos & 15));
+    }
+}
+
+// K5 for word flags: one lane per read; high = HIGH bits inside the read, total = HIGH or LOW bits inside it
+__global__ void __launch_bounds__(256) k_reduce_words(const uint32_t *__restrict__ wflags, const uint64_t *__restrict__ offsets,
+                                                      uint32_t n_reads, int32_t *__restrict__ high, int32_t *__restrict__ total)
+{
+    uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    uint64_t a = offsets[r], b = offsets[r + 1];
+    uint32_t h = 0, t = 0;
+    for (uint64_t w = a >> 4; w * 16 < b; w++) {
+        uint32_t f = wflags[w];
+        uint32_t m = 0xffffu;
+        if (w * 16 < a) m &= 0xffffu << (a - w * 16);
+        if (w * 16 + 16 > b) m &= 0xffffu >> (w * 16 + 16 - b);
+        uint32_t hb = f & m, lb = (f >> 16) & m;
+        h += __popc(hb);
+        t += __popc(hb | lb);
+    }
+    high[r] = (int32_t)h;
+    total[r] = (int32_t)t;
 }
 
 // Growth (expand_local_hash_table, normalise_kmers_multi_large.c:1055-1108): every stored key moves to a table
@@ -738,9 +1009,7 @@ struct nkml_ctx {
     uint8_t *d_seq;
     uint64_t *d_offsets;
     uint32_t *d_packed, *d_startbits;
-    void *d_keys;
-    uint8_t *d_flags;
-    unsigned long long *d_slot_of; // hashed: slot index of each LOW occurrence
+    uint32_t *d_wflags;     // per packed word: HIGH bits (low half) and LOW bits (high half) of its 16 windows
     int32_t *d_high, *d_total;
 
     // per-chunk buffers
@@ -796,6 +1065,7 @@ int fail(nkml_ctx *ctx, int code, const char *fmt, ...)
 
 inline uint32_t blocks_for(uint64_t n, uint32_t per_block = 256) { return (uint32_t)((n + per_block - 1) / per_block); }
 constexpr uint32_t GRID_PERSIST = 256 * 8; // 8 workgroups of 256 lanes per CU, grid-stride beyond
+constexpr uint32_t GRID_FUSED = 256 * 8;
 
 uint64_t default_hashed_capacity(int memory_gb)
 {
@@ -870,14 +1140,24 @@ int ensure_capacity(nkml_ctx *c, uint64_t incoming)
     return NKML_OK;
 }
 
-// K0-K2 on the context's stream.
-int run_kmerise(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, void *d_keys)
+// K0 + K1 on the context's stream: read starts and 2-bit packing of one batch.
+int run_prepare(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases)
 {
     uint64_t n_words = (n_bases + 15) / 16;
     HIPCHK(c, hipMemsetAsync(c->d_startbits, 0, (n_words + 4) * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_packed + n_words, 0, 4 * sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_mark_starts, blocks_for((uint64_t)n_reads + 1), 256, 0, c->stream, d_offsets, n_reads, c->d_startbits);
     hipLaunchKernelGGL(k_pack, blocks_for(n_words), 256, 0, c->stream, d_seq, n_bases, c->d_packed, n_words, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+// K0-K2: keys materialised per base position (the staged form used by the sharded path).
+int run_kmerise(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, void *d_keys)
+{
+    int rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    const uint64_t n_words = (n_bases + 15) / 16;
     const int k = c->cfg.ksize;
     const uint32_t g = blocks_for(n_words);
     if (c->key_bytes == 4) {
@@ -895,63 +1175,13 @@ int run_kmerise(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, ui
     return NKML_OK;
 }
 
-// K3 + K4 over keys [0, n) in chunks; n is a multiple of 16.  Per chunk: count, collect the occurrences of the
-// k-mers that crossed, make the newly saturated k-mers visible to the next chunk - all enqueued without
-// waiting.  One wait per batch, for the number of crossing occurrences, then sort + rank them.
-int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, bool seeding)
+// End of a batch's counting passes: the one host wait (for the number of crossing occurrences), then sort + rank.
+// Exactly one of d_flags (byte flags per position) / d_wflags (word flags) is given.
+int finish_counting(nkml_ctx *c, int n_ev, uint64_t keys_timed, uint8_t *d_flags, uint32_t *d_wflags)
 {
     const uint32_t depth = (uint32_t)c->cfg.depth;
-    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
     int rc;
-    if ((rc = ensure_capacity(c, n)) != NKML_OK) return rc;
-    if ((n >> c->posbits) != 0 && n != (1ull << c->posbits)) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
-    int n_ev = 0;
-    uint64_t keys_timed = 0;
-    for (uint64_t a = 0; a < n; a += c->chunk) {
-        uint64_t len = n - a < c->chunk ? n - a : c->chunk;
-        if (seeding) {
-            if (c->direct)
-                hipLaunchKernelGGL(k_seed_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len, c->counts, c->d_ctr);
-            else
-                hipLaunchKernelGGL(k_seed_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, c->slots,
-                                   c->capacity - 1, c->d_ctr);
-            HIPCHK(c, hipGetLastError());
-            continue;
-        }
-        const bool timed = profile && n_ev < 64;
-        if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
-        if (c->direct) {
-            hipLaunchKernelGGL(k_count_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len / 4, d_flags + a, c->counts,
-                               c->sat, c->filter, depth, c->extra, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
-        } else {
-            hipLaunchKernelGGL(k_count_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, d_flags + a,
-                               c->d_slot_of, c->slots, c->capacity - 1, c->filter, depth, (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0, c->d_ctr,
-                               (unsigned long long *)c->d_list_sat,
-                               (unsigned long long *)c->d_list_cross);
-        }
-        HIPCHK(c, hipGetLastError());
-        if (timed) {
-            HIPCHK(c, hipEventRecord(c->ev[2 * n_ev + 1], c->stream));
-            n_ev++;
-            keys_timed += len;
-        }
-        if (c->direct) {
-            hipLaunchKernelGGL(k_collect_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, d_flags + a, len / 4, a, c->filter,
-                               c->counts, depth, c->posbits, c->d_occ, c->d_ctr);
-            hipLaunchKernelGGL(k_apply_direct, 256, 256, 0, c->stream, (const uint32_t *)c->d_list_sat, (const uint32_t *)c->d_list_cross, c->sat,
-                               c->d_ctr);
-        } else {
-            hipLaunchKernelGGL(k_collect_hashed, GRID_PERSIST, 256, 0, c->stream, d_flags + a, c->d_slot_of, len, a, c->filter, c->slots, depth,
-                               c->posbits, c->d_occ, c->d_ctr);
-            hipLaunchKernelGGL(k_apply_hashed, 256, 256, 0, c->stream, (const unsigned long long *)c->d_list_sat,
-                               (const unsigned long long *)c->d_list_cross, c->slots, c->d_ctr);
-        }
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_end_chunk, 1, 1, 0, c->stream, c->d_ctr);
-        HIPCHK(c, hipGetLastError());
-    }
-    if ((rc = fetch_counters(c)) != NKML_OK) return rc; // the batch's one wait
+    if ((rc = fetch_counters(c)) != NKML_OK) return rc;
     if (c->h_ctr->probe_overflow) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
     for (int i = 0; i < n_ev; i++) {
         float ms = 0;
@@ -964,15 +1194,22 @@ int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, boo
     if (n_occ) {
         int idbits = 0;
         while (idbits < 64 && (c->capacity - 1) >> idbits) idbits++;
+        if (c->posbits + idbits > 64) return fail(c, NKML_E_ARG, "table and batch too large for 64-bit (k-mer, position) composites");
         size_t tmp = c->sort_tmp_bytes;
         HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, tmp, c->d_occ, c->d_occ_sorted, (size_t)n_occ, 0u, (unsigned)(c->posbits + idbits),
                                            c->stream));
-        if (c->direct)
-            hipLaunchKernelGGL((k_rank<DirectTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
-                               DirectTable{c->counts}, depth, d_flags);
-        else
-            hipLaunchKernelGGL((k_rank<HashedTable>), blocks_for(n_occ), 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits,
-                               HashedTable{c->slots}, depth, d_flags);
+        const uint32_t g = blocks_for(n_occ);
+        if (d_flags) {
+            if (c->direct)
+                hipLaunchKernelGGL((k_rank<DirectTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, DirectTable{c->counts}, depth, d_flags);
+            else
+                hipLaunchKernelGGL((k_rank<HashedTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, HashedTable{c->slots}, depth, d_flags);
+        } else {
+            if (c->direct)
+                hipLaunchKernelGGL((k_rank_words<DirectTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, DirectTable{c->counts}, depth, d_wflags);
+            else
+                hipLaunchKernelGGL((k_rank_words<HashedTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, HashedTable{c->slots}, depth, d_wflags);
+        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemsetAsync(&c->d_ctr->n_occ, 0, sizeof(unsigned int), c->stream));
         c->crossing_occ += n_occ;
@@ -980,12 +1217,132 @@ int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags, boo
     return NKML_OK;
 }
 
-int run_reduce(nkml_ctx *c, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high,
-               int32_t *d_total)
+// after every chunk's counting pass: newly saturated k-mers become visible, filter and list lengths restart
+int end_chunk(nkml_ctx *c)
+{
+    if (c->direct)
+        hipLaunchKernelGGL(k_apply_direct, 256, 256, 0, c->stream, (const uint32_t *)c->d_list_sat, (const uint32_t *)c->d_list_cross, c->sat, c->d_ctr);
+    else
+        hipLaunchKernelGGL(k_apply_hashed, 256, 256, 0, c->stream, (const unsigned long long *)c->d_list_sat,
+                           (const unsigned long long *)c->d_list_cross, c->slots, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_end_chunk, 1, 1, 0, c->stream, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+// Staged K3 + K4 over a key array [0, n) in chunks; n is a multiple of 16.  Per chunk: count, collect the occurrences
+// of the k-mers that crossed, make the newly saturated k-mers visible to the next chunk - all enqueued without
+// waiting.
+int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags)
+{
+    const uint32_t depth = (uint32_t)c->cfg.depth;
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0;
+    const int exact = (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0;
+    int rc;
+    if ((rc = ensure_capacity(c, n)) != NKML_OK) return rc;
+    if (n > (1ull << c->posbits)) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
+    int n_ev = 0;
+    uint64_t keys_timed = 0;
+    for (uint64_t a = 0; a < n; a += c->chunk) {
+        uint64_t len = n - a < c->chunk ? n - a : c->chunk;
+        const bool timed = profile && n_ev < 64;
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
+        if (c->direct)
+            hipLaunchKernelGGL(k_count_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, len / 4, d_flags + a, c->counts,
+                               c->sat, c->filter, depth, c->extra, c->d_ctr, (uint32_t *)c->d_list_sat, (uint32_t *)c->d_list_cross);
+        else
+            hipLaunchKernelGGL(k_count_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, len, d_flags + a, c->slots,
+                               c->capacity - 1, c->filter, depth, exact, c->d_ctr, (unsigned long long *)c->d_list_sat,
+                               (unsigned long long *)c->d_list_cross);
+        HIPCHK(c, hipGetLastError());
+        if (timed) {
+            HIPCHK(c, hipEventRecord(c->ev[2 * n_ev + 1], c->stream));
+            n_ev++;
+            keys_timed += len;
+        }
+        if (c->direct)
+            hipLaunchKernelGGL(k_collect_direct, GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys + a, d_flags + a, len / 4, a, c->filter,
+                               c->counts, depth, c->posbits, c->d_occ, c->d_ctr);
+        else
+            hipLaunchKernelGGL(k_collect_hashed, GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys + a, d_flags + a, len, a,
+                               c->filter, c->slots, c->capacity - 1, depth, c->posbits, c->d_occ, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = end_chunk(c)) != NKML_OK) return rc;
+    }
+    return finish_counting(c, n_ev, keys_timed, d_flags, nullptr);
+}
+
+// Fused K2+K3+K4 over the prepared batch (packed words), the single-GPU path: keys live in registers only.
+int run_fused(nkml_ctx *c, uint64_t n_bases, bool seeding)
+{
+    const uint32_t depth = (uint32_t)c->cfg.depth;
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
+    const int exact = (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0;
+    const int k = c->cfg.ksize;
+    const bool canon = c->cfg.canonical != 0;
+    const uint64_t n_words = (n_bases + 15) / 16, mask = c->capacity - 1;
+    int rc;
+    if ((rc = ensure_capacity(c, n_words * 16)) != NKML_OK) return rc;
+    if (seeding) {
+#define SEED_LAUNCH(CANON, DIRECT) hipLaunchKernelGGL((k_seed_words<CANON, DIRECT>), GRID_PERSIST, 256, 0, c->stream, c->d_packed, c->d_startbits, \
+                                                      n_bases, n_words, k, c->counts, c->slots, mask, c->d_ctr)
+        if (c->direct) { if (canon) SEED_LAUNCH(true, true); else SEED_LAUNCH(false, true); }
+        else { if (canon) SEED_LAUNCH(true, false); else SEED_LAUNCH(false, false); }
+#undef SEED_LAUNCH
+        HIPCHK(c, hipGetLastError());
+        return finish_counting(c, 0, 0, nullptr, c->d_wflags);
+    }
+    int n_ev = 0;
+    uint64_t keys_timed = 0;
+    const uint64_t chunk_words = c->chunk / 16;
+    for (uint64_t wa = 0; wa < n_words; wa += chunk_words) {
+        const uint64_t wb = wa + chunk_words < n_words ? wa + chunk_words : n_words;
+        const bool timed = profile && n_ev < 64;
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
+        if (c->direct) {
+#define COUNT_LAUNCH(CANON) hipLaunchKernelGGL((k_count_words_direct<CANON>), GRID_FUSED, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, wa, wb, k, \
+                                               c->d_wflags, c->counts, c->sat, c->filter, depth, c->extra, c->d_ctr, (uint32_t *)c->d_list_sat,          \
+                                               (uint32_t *)c->d_list_cross)
+            if (canon) COUNT_LAUNCH(true); else COUNT_LAUNCH(false);
+#undef COUNT_LAUNCH
+        } else {
+#define COUNT_LAUNCH(CANON) hipLaunchKernelGGL((k_count_words_hashed<CANON>), GRID_FUSED, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, wa, wb, k, \
+                                               c->d_wflags, c->slots, mask, c->filter, depth, exact, c->d_ctr, (unsigned long long *)c->d_list_sat,      \
+                                               (unsigned long long *)c->d_list_cross)
+            if (canon) COUNT_LAUNCH(true); else COUNT_LAUNCH(false);
+#undef COUNT_LAUNCH
+        }
+        HIPCHK(c, hipGetLastError());
+        if (timed) {
+            HIPCHK(c, hipEventRecord(c->ev[2 * n_ev + 1], c->stream));
+            n_ev++;
+            keys_timed += (wb - wa) * 16;
+        }
+#define COLLECT_LAUNCH(CANON, DIRECT) hipLaunchKernelGGL((k_collect_words<CANON, DIRECT>), GRID_FUSED, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, \
+                                                         wa, wb, k, c->d_wflags, c->filter, c->counts, c->slots, mask, depth, c->posbits, c->d_occ, c->d_ctr)
+        if (c->direct) { if (canon) COLLECT_LAUNCH(true, true); else COLLECT_LAUNCH(false, true); }
+        else { if (canon) COLLECT_LAUNCH(true, false); else COLLECT_LAUNCH(false, false); }
+#undef COLLECT_LAUNCH
+        HIPCHK(c, hipGetLastError());
+        if ((rc = end_chunk(c)) != NKML_OK) return rc;
+    }
+    return finish_counting(c, n_ev, keys_timed, nullptr, c->d_wflags);
+}
+
+int run_reduce(nkml_ctx *c, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high, int32_t *d_total)
 {
     if (n_reads == 0) return NKML_OK;
-    (void)d_keys;
     hipLaunchKernelGGL(k_reduce_reads, blocks_for(n_reads, 4), 256, 0, c->stream, d_flags, d_offsets, n_reads, d_high, d_total);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int run_reduce_words(nkml_ctx *c, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high, int32_t *d_total)
+{
+    if (n_reads == 0) return NKML_OK;
+    hipLaunchKernelGGL(k_reduce_words, blocks_for(n_reads), 256, 0, c->stream, c->d_wflags, d_offsets, n_reads, d_high, d_total);
     HIPCHK(c, hipGetLastError());
     return NKML_OK;
 }
@@ -1085,9 +1442,7 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     CREATE_HIP(hipMalloc(&c->d_offsets, ((uint64_t)cfg->max_batch_reads + 1) * sizeof(uint64_t)));
     CREATE_HIP(hipMalloc(&c->d_packed, (c->max_words + 4) * sizeof(uint32_t)));
     CREATE_HIP(hipMalloc(&c->d_startbits, (c->max_words + 4) * sizeof(uint32_t)));
-    CREATE_HIP(hipMalloc(&c->d_keys, npos * c->key_bytes));
-    CREATE_HIP(hipMalloc(&c->d_flags, npos));
-    if (!c->direct) CREATE_HIP(hipMalloc(&c->d_slot_of, (uint64_t)c->chunk * sizeof(unsigned long long)));
+    CREATE_HIP(hipMalloc(&c->d_wflags, (c->max_words + 4) * sizeof(uint32_t)));
     CREATE_HIP(hipMalloc(&c->d_high, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
     CREATE_HIP(hipMalloc(&c->d_total, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
     const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
@@ -1120,7 +1475,7 @@ void nkml_destroy(nkml_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
-    hipFree(c->d_keys); hipFree(c->d_flags); hipFree(c->d_slot_of); hipFree(c->d_high); hipFree(c->d_total);
+    hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
     hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
     hipFree(c->d_ctr);
@@ -1200,7 +1555,7 @@ int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
 {
     if (!c || !d_keys || !d_flags || (n_keys & 15)) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    return run_count(c, d_keys, n_keys, d_flags, false);
+    return run_count(c, d_keys, n_keys, d_flags);
 }
 
 int nkml_reduce_reads_device(nkml_ctx *c, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads,
@@ -1208,7 +1563,7 @@ int nkml_reduce_reads_device(nkml_ctx *c, const void *d_keys, const uint8_t *d_f
 {
     if (!c || !d_keys || !d_flags || !d_offsets || !d_high || !d_total) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    return run_reduce(c, d_keys, d_flags, d_offsets, n_reads, d_high, d_total);
+    return run_reduce(c, d_flags, d_offsets, n_reads, d_high, d_total);
 }
 
 int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
@@ -1219,11 +1574,10 @@ int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_off
     if (rc != NKML_OK) return rc;
     if (n_reads == 0) return NKML_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if ((rc = run_kmerise(c, d_seq, d_offsets, n_reads, n_bases, c->d_keys)) != NKML_OK) return rc;
-    uint64_t n_keys = (n_bases + 15) / 16 * 16;
-    if ((rc = run_count(c, c->d_keys, n_keys, c->d_flags, false)) != NKML_OK) return rc;
+    if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+    if ((rc = run_fused(c, n_bases, false)) != NKML_OK) return rc;
     if ((rc = check_bad_bases(c)) != NKML_OK) return rc;
-    return run_reduce(c, c->d_keys, c->d_flags, d_offsets, n_reads, d_high, d_total);
+    return run_reduce_words(c, d_offsets, n_reads, d_high, d_total);
 }
 
 static int stage_host_batch(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads, uint64_t *n_bases_out)
@@ -1281,8 +1635,8 @@ int nkml_seed(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t
     uint64_t n_bases = 0;
     int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
     if (rc != NKML_OK) return rc;
-    if ((rc = run_kmerise(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->d_keys)) != NKML_OK) return rc;
-    if ((rc = run_count(c, c->d_keys, (n_bases + 15) / 16 * 16, c->d_flags, true)) != NKML_OK) return rc;
+    if ((rc = run_prepare(c, c->d_seq, c->d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+    if ((rc = run_fused(c, n_bases, true)) != NKML_OK) return rc;
     return check_bad_bases(c);
 }
 
