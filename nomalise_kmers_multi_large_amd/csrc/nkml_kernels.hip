@@ -956,6 +956,8 @@ __global__ void __launch_bounds__(256) k_unroute_flags(const uint8_t *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_sent; i += stride) flags[send_src[i]] = recv_flags[i];
 }
 
+#include "nkml_partition.inc"
+
 // table dump helpers
 __global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ extra, uint64_t cap, unsigned long long *codes,
                                                      uint32_t *cnts, uint64_t max_entries, unsigned long long *n_out)
@@ -1000,6 +1002,18 @@ struct nkml_ctx {
     uint32_t *sat;          // direct: saturation bitmap
     uint32_t *extra;        // direct, NKML_F_EXACT_COUNTS: occurrences counted after saturation
     uint32_t *filter;       // crossing filter (both table kinds)
+    // partitioned counting (k <= 15, depth <= 127): one byte per k-mer and the buffers of the two radix passes
+    bool partitioned;
+    uint8_t *pt_table;
+    uint32_t *pt_keys, *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
+    uint16_t *pt_keysB;
+    uint8_t *pt_flags, *pt_flagsA, *pt_flagsB;
+    void *pt_scan_tmp;
+    size_t pt_scan_tmp_bytes;
+    uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
+    uint64_t pt_timed_keys;
+    bool pt_timing_pending;
+    double pt_bucket_ms;
     Slot *slots;            // hashed
     uint64_t capacity;      // slots / counters
     uint64_t resizes;
@@ -1079,6 +1093,32 @@ uint64_t default_hashed_capacity(int memory_gb)
 
 int alloc_table(nkml_ctx *c)
 {
+    if (c->partitioned) {
+        c->capacity = 1ull << (2 * c->cfg.ksize);
+        const uint64_t bytes = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+        HIPCHK(c, hipMalloc(&c->pt_table, bytes));
+        const uint64_t npos = c->max_words * 16;
+        c->pt_tiles_a = (npos + PT_TILE - 1) / PT_TILE;
+        c->pt_tiles_b = c->pt_tiles_a + 256 + 1;
+        const uint64_t na = (c->pt_tiles_b + 1) * PT_TILE;
+        HIPCHK(c, hipMalloc(&c->pt_keys, npos * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_flags, npos));
+        HIPCHK(c, hipMalloc(&c->pt_keysA, na * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_flagsA, na));
+        HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
+        HIPCHK(c, hipMalloc(&c->pt_flagsB, npos));
+        HIPCHK(c, hipMalloc(&c->pt_histA, (256 * c->pt_tiles_a + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_scanA, (256 * c->pt_tiles_a + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_histB, (256 * c->pt_tiles_b + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_scanB, (256 * c->pt_tiles_b + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
+        size_t tmp = 0;
+        HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, c->pt_histB, c->pt_scanB, 0u, (size_t)(256 * c->pt_tiles_b + 1), rocprim::plus<uint32_t>(), c->stream));
+        c->pt_scan_tmp_bytes = tmp ? tmp : 256;
+        HIPCHK(c, hipMalloc(&c->pt_scan_tmp, c->pt_scan_tmp_bytes));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        return NKML_OK;
+    }
     if (c->direct) {
         c->capacity = 1ull << (2 * c->cfg.ksize);
         HIPCHK(c, hipMalloc(&c->counts, c->capacity * sizeof(uint32_t)));
@@ -1095,7 +1135,10 @@ int alloc_table(nkml_ctx *c)
 
 int clear_table(nkml_ctx *c)
 {
-    if (c->direct) {
+    if (c->partitioned) {
+        const uint64_t bytes = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+        HIPCHK(c, hipMemsetAsync(c->pt_table, 0, bytes, c->stream));
+    } else if (c->direct) {
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, hipMemsetAsync(c->counts, 0, c->capacity * sizeof(uint32_t), c->stream));
         HIPCHK(c, hipMemsetAsync(c->sat, 0, bm, c->stream));
@@ -1103,7 +1146,7 @@ int clear_table(nkml_ctx *c)
     } else {
         HIPCHK(c, hipMemsetAsync(c->slots, 0, c->capacity * sizeof(Slot), c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
+    if (c->filter) HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->crossing_kmers = c->crossing_occ = 0;
     c->count_ms = 0;
@@ -1339,6 +1382,71 @@ int run_reduce(nkml_ctx *c, const uint8_t *d_flags, const uint64_t *d_offsets, u
     return NKML_OK;
 }
 
+// Partitioned counting of a key array (k <= 15): two stable radix passes, one workgroup per bucket, two reverse
+// passes for the flags.  Nothing here waits for the device.
+int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint8_t *d_flags, bool seeding)
+{
+    if (n == 0) return NKML_OK;
+    if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
+    const uint64_t ta = (n + PT_TILE - 1) / PT_TILE;       // first-pass tiles of this batch
+    const uint64_t tb = ta + 256 + 1;                      // bound on second-pass tiles (each group padded to a tile)
+    const size_t ea = 256 * ta + 1, eb = 256 * tb + 1;
+    const int shift_a = PT_LOWBITS, shift_b = PT_LOWBITS + 8;
+    const uint32_t *n_a = c->pt_pad + 256;                 // padded length of the first pass's output, on the device
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + ea - 1, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + eb - 1, 0, sizeof(uint32_t), c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_histA);
+    size_t tmp = c->pt_scan_tmp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->pt_scan_tmp, tmp, c->pt_histA, c->pt_scanA, 0u, ea, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(k_pt_pad, 1, 64, 0, c->stream, c->pt_scanA, ta, c->pt_pad);
+    hipLaunchKernelGGL(k_pt_zero_gaps, 256, 256, 0, c->stream, c->pt_scanA, ta, c->pt_pad, c->pt_keysA);
+    hipLaunchKernelGGL((k_pt_scatter<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
+                       c->pt_pad, c->pt_keysA);
+    hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_histB);
+    HIPCHK(c, hipGetLastError());
+    tmp = c->pt_scan_tmp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->pt_scan_tmp, tmp, c->pt_histB, c->pt_scanB, 0u, eb, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL((k_pt_scatter<uint16_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
+                       (const uint32_t *)nullptr, c->pt_keysB);
+    const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
+                       (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (!seeding) {
+        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
+                           (const uint32_t *)nullptr, c->pt_flagsB, c->pt_flagsA, (uint8_t)0);
+        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
+                           c->pt_pad, c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (profile) {
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->pt_timed_keys = n;
+        c->pt_timing_pending = true;
+    }
+    return NKML_OK;
+}
+
+// read back the event pairs of the last partitioned batch (after the stream has been waited for)
+int collect_partition_timing(nkml_ctx *c)
+{
+    if (!c->pt_timing_pending) return NKML_OK;
+    HIPCHK(c, hipEventSynchronize(c->ev[1]));
+    float whole = 0, bucket = 0;
+    HIPCHK(c, hipEventElapsedTime(&whole, c->ev[0], c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&bucket, c->ev[2], c->ev[3]));
+    c->count_ms += whole;
+    c->pt_bucket_ms += bucket;
+    c->count_launches++;
+    c->count_keys += c->pt_timed_keys;
+    c->pt_timing_pending = false;
+    return NKML_OK;
+}
+
 int run_reduce_words(nkml_ctx *c, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high, int32_t *d_total)
 {
     if (n_reads == 0) return NKML_OK;
@@ -1405,6 +1513,10 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     memset(c, 0, sizeof *c);
     c->cfg = *cfg;
     c->direct = cfg->ksize <= 16;
+    {
+        const char *env = getenv("NKML_PARTITIONED");
+        c->partitioned = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS) && env && env[0] == '1';
+    }
     c->key_bytes = c->direct ? 4 : 8;
     uint32_t chunk = cfg->chunk_bases ? cfg->chunk_bases : (32u << 20);
     chunk = (chunk + 63) & ~63u;
@@ -1474,6 +1586,9 @@ void nkml_destroy(nkml_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
+    hipFree(c->pt_table); hipFree(c->pt_keys); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flags); hipFree(c->pt_flagsA);
+    hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
+    hipFree(c->pt_scan_tmp);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
@@ -1528,7 +1643,7 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     memset(out, 0, sizeof *out);
     out->unique_kmers = c->h_ctr->unique;
     out->capacity = c->capacity;
-    out->table_bytes = c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
+    out->table_bytes = c->partitioned ? c->capacity : c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
     out->kmers_counted = c->h_ctr->counted;
     out->kmers_saturated = c->h_ctr->saturated;
     out->crossing_kmers = c->h_ctr->total_cross;
@@ -1555,6 +1670,7 @@ int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
 {
     if (!c || !d_keys || !d_flags || (n_keys & 15)) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->partitioned) return run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, d_flags, false);
     return run_count(c, d_keys, n_keys, d_flags);
 }
 
@@ -1574,6 +1690,15 @@ int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_off
     if (rc != NKML_OK) return rc;
     if (n_reads == 0) return NKML_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->partitioned) {
+        const uint64_t n_keys = (n_bases + 15) / 16 * 16;
+        if ((rc = run_kmerise(c, d_seq, d_offsets, n_reads, n_bases, c->pt_keys)) != NKML_OK) return rc;
+        if ((rc = run_count_partitioned(c, c->pt_keys, n_keys, c->pt_flags, false)) != NKML_OK) return rc;
+        if ((rc = run_reduce(c, c->pt_flags, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
+        if ((rc = fetch_counters(c)) != NKML_OK) return rc; // bad-base tally; the one wait of the batch
+        if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
+        return check_bad_bases(c);
+    }
     if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
     if ((rc = run_fused(c, n_bases, false)) != NKML_OK) return rc;
     if ((rc = check_bad_bases(c)) != NKML_OK) return rc;
@@ -1635,6 +1760,12 @@ int nkml_seed(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t
     uint64_t n_bases = 0;
     int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
     if (rc != NKML_OK) return rc;
+    if (c->partitioned) {
+        if ((rc = run_kmerise(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->pt_keys)) != NKML_OK) return rc;
+        if ((rc = run_count_partitioned(c, c->pt_keys, (n_bases + 15) / 16 * 16, c->pt_flags, true)) != NKML_OK) return rc;
+        if ((rc = fetch_counters(c)) != NKML_OK) return rc;
+        return check_bad_bases(c);
+    }
     if ((rc = run_prepare(c, c->d_seq, c->d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
     if ((rc = run_fused(c, n_bases, true)) != NKML_OK) return rc;
     return check_bad_bases(c);
@@ -1738,7 +1869,9 @@ int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max
     HIPCHK(c, hipMalloc(&d_cnts, room * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc(&d_n, sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
-    if (c->direct)
+    if (c->partitioned)
+        hipLaunchKernelGGL(k_pt_dump, GRID_PERSIST, 256, 0, c->stream, c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
+    else if (c->direct)
         hipLaunchKernelGGL(k_dump_direct, GRID_PERSIST, 256, 0, c->stream, c->counts, c->extra, c->capacity, d_codes, d_cnts, max_entries, d_n);
     else
         hipLaunchKernelGGL(k_dump_hashed, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, d_codes, d_cnts, max_entries, d_n);
