@@ -1116,7 +1116,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, c->pt_histB, c->pt_scanB, 0u, (size_t)(256 * c->pt_tiles_b + 1), rocprim::plus<uint32_t>(), c->stream));
         c->pt_scan_tmp_bytes = tmp ? tmp : 256;
         HIPCHK(c, hipMalloc(&c->pt_scan_tmp, c->pt_scan_tmp_bytes));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         return NKML_OK;
     }
     if (c->direct) {
@@ -1412,7 +1412,9 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint8
                        (const uint32_t *)nullptr, c->pt_keysB);
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
+    hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, 256, 0, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
+                       (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+    hipLaunchKernelGGL(k_pt_count_bucket_big, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipGetLastError());

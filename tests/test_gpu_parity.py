@@ -268,3 +268,70 @@ def test_sharded_stages_on_one_gpu(nk, oracle_lib):
         assert sum(e.stats()["unique_kmers"] for e in engines) == o.unique
         for e in engines:
             e.nk.close()
+
+
+# ---- the partitioned counting path (k <= 15, depth <= 127; NKML_PARTITIONED=1) against the same checks -----------
+class partitioned_mode:
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("NKML_PARTITIONED")
+        os.environ["NKML_PARTITIONED"] = "1" if self.on else "0"
+
+    def __exit__(self, *exc):
+        import os
+        if self.old is None:
+            os.environ.pop("NKML_PARTITIONED", None)
+        else:
+            os.environ["NKML_PARTITIONED"] = self.old
+
+
+@pytest.mark.parametrize("k,depth,canonical", [(5, 2, False), (7, 5, True), (9, 100, True), (13, 3, False), (15, 3, False), (15, 100, True)])
+def test_partitioned_random_reads(nk, oracle_lib, k, depth, canonical):
+    rng = np.random.default_rng(4000 + k * 7 + depth)
+    reads = random_reads(rng, 600, k, 4 * k + 40, b"AC") + random_reads(rng, 600, k, 200, b"ACGT", 0.01) \
+        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"G" * 64, b"C" * 33, b"N" * 40] * 3
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    o = oracle_lib(k, depth, canonical)
+    want = [o.read(r) for r in reads]
+    with partitioned_mode(True), nk.KmerNormaliser(k, depth, 0.9, canonical, max_batch_reads=700, max_batch_bases=60000) as g:
+        ok, high, total = g.process_sequence_single(reads)
+        np.testing.assert_array_equal(high, [w[1] for w in want])
+        np.testing.assert_array_equal(total, [w[2] for w in want])
+        assert g.unique_kmers == o.unique
+        st = g.stats()
+        assert st["kmers_counted"] == int(total.sum()) and st["crossing_kmers"] == 0  # no atomic-path bookkeeping ran
+
+
+@pytest.mark.parametrize("on", [False, True])
+def test_heavy_bucket_one_kmer_many_times(nk, oracle_lib, on):
+    """Low-complexity flood: one k-mer hundreds of thousands of times in a batch (more than 16-bit counters hold),
+    its threshold crossed in the middle of a read, plus near-copies landing in the same table bucket."""
+    k, depth = 15, 100
+    reads = [b"G" * 150] * 1500 + [b"G" * 120 + b"C" + b"G" * 29] * 300 + [b"G" * 40 + b"T" + b"G" * 60] * 200 + [b"ACGT" * 30] * 50
+    rng = np.random.default_rng(8)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    o = oracle_lib(k, depth)
+    want = [o.read(r) for r in reads]
+    with partitioned_mode(on), nk.KmerNormaliser(k, depth, 0.9, max_batch_reads=4096, max_batch_bases=1 << 20) as g:
+        ok, high, total = g.process_sequence_single(reads)
+        np.testing.assert_array_equal(high, [w[1] for w in want])
+        np.testing.assert_array_equal(total, [w[2] for w in want])
+        assert g.unique_kmers == o.unique
+
+
+def test_partitioned_equals_atomic_path_on_synthetic_pairs(nk):
+    """Both counting paths on the same 150 bp synthetic pairs in several batches: identical per-read counters."""
+    from nomalise_kmers_multi_large_amd import synth
+    res = []
+    for on in (False, True):
+        with partitioned_mode(on), nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=100000, max_batch_bases=100000 * 150) as g:
+            out = []
+            for c1, c2 in synth.pair_blocks(150000, seed=5, transcripts=100, block=50000):
+                out.append(g.process_batch(*synth.interleave(c1, c2)))
+            res.append((np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out]), g.unique_kmers))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
