@@ -1402,13 +1402,13 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint8
     HIPCHK(c, rocprim::exclusive_scan(c->pt_scan_tmp, tmp, c->pt_histA, c->pt_scanA, 0u, ea, rocprim::plus<uint32_t>(), c->stream));
     hipLaunchKernelGGL(k_pt_pad, 1, 64, 0, c->stream, c->pt_scanA, ta, c->pt_pad);
     hipLaunchKernelGGL(k_pt_zero_gaps, 256, 256, 0, c->stream, c->pt_scanA, ta, c->pt_pad, c->pt_keysA);
-    hipLaunchKernelGGL((k_pt_scatter<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
+    hipLaunchKernelGGL((k_pt_scatter<uint32_t>), (uint32_t)ta, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
                        c->pt_pad, c->pt_keysA);
     hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_histB);
     HIPCHK(c, hipGetLastError());
     tmp = c->pt_scan_tmp_bytes;
     HIPCHK(c, rocprim::exclusive_scan(c->pt_scan_tmp, tmp, c->pt_histB, c->pt_scanB, 0u, eb, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL((k_pt_scatter<uint16_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
+    hipLaunchKernelGGL((k_pt_scatter<uint16_t>), (uint32_t)tb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
                        (const uint32_t *)nullptr, c->pt_keysB);
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1419,9 +1419,9 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint8
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
-        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
+        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)tb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
                            (const uint32_t *)nullptr, c->pt_flagsB, c->pt_flagsA, (uint8_t)0);
-        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
+        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)ta, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
                            c->pt_pad, c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW);
         HIPCHK(c, hipGetLastError());
     }
