@@ -1006,10 +1006,10 @@ struct nkml_ctx {
     bool partitioned;
     uint8_t *pt_table;
     uint32_t *pt_keys, *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
-    uint16_t *pt_keysB;
+    uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
+    uint16_t *pt_keysB, *pt_sposA, *pt_sposB; // spos / sdig: what the forward passes leave for the reverse passes
+    uint8_t *pt_sdigA, *pt_sdigB;
     uint8_t *pt_flags, *pt_flagsA, *pt_flagsB;
-    void *pt_scan_tmp;
-    size_t pt_scan_tmp_bytes;
     uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
     uint64_t pt_timed_keys;
     bool pt_timing_pending;
@@ -1107,15 +1107,19 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_flagsA, na));
         HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
         HIPCHK(c, hipMalloc(&c->pt_flagsB, npos));
-        HIPCHK(c, hipMalloc(&c->pt_histA, (256 * c->pt_tiles_a + 1) * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->pt_scanA, (256 * c->pt_tiles_a + 1) * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->pt_histB, (256 * c->pt_tiles_b + 1) * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->pt_scanB, (256 * c->pt_tiles_b + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_sposA, c->pt_tiles_a * PT_TILE * sizeof(uint16_t)));
+        HIPCHK(c, hipMalloc(&c->pt_sdigA, c->pt_tiles_a * PT_TILE));
+        HIPCHK(c, hipMalloc(&c->pt_sposB, na * sizeof(uint16_t)));
+        HIPCHK(c, hipMalloc(&c->pt_sdigB, na));
+        // histograms and their scans: one row of 256 per tile plus the all-zero row after the last tile
+        HIPCHK(c, hipMalloc(&c->pt_histA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_scanA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_histB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_scanB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
-        size_t tmp = 0;
-        HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, c->pt_histB, c->pt_scanB, 0u, (size_t)(256 * c->pt_tiles_b + 1), rocprim::plus<uint32_t>(), c->stream));
-        c->pt_scan_tmp_bytes = tmp ? tmp : 256;
-        HIPCHK(c, hipMalloc(&c->pt_scan_tmp, c->pt_scan_tmp_bytes));
+        HIPCHK(c, hipMalloc(&c->pt_startB, 260 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_totals, 256 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_chunks, 256 * ((c->pt_tiles_b + 1 + PT_CH - 1) / PT_CH + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         return NKML_OK;
     }
@@ -1384,45 +1388,68 @@ int run_reduce(nkml_ctx *c, const uint8_t *d_flags, const uint64_t *d_offsets, u
 
 // Partitioned counting of a key array (k <= 15): two stable radix passes, one workgroup per bucket, two reverse
 // passes for the flags.  Nothing here waits for the device.
-int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint8_t *d_flags, bool seeding)
+// d_keys == nullptr: the keys of the first pass are recomputed from the context's packed words (n_bases of them
+// prepared); d_flags == nullptr: the result is the context's word flags (one word per 16 positions).
+int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
 {
     if (n == 0) return NKML_OK;
     if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
     const uint64_t ta = (n + PT_TILE - 1) / PT_TILE;       // first-pass tiles of this batch
     const uint64_t tb = ta + 256 + 1;                      // bound on second-pass tiles (each group padded to a tile)
-    const size_t ea = 256 * ta + 1, eb = 256 * tb + 1;
+    const uint64_t ra = ta + 1, rb = tb + 1;               // histogram rows: the tiles and the all-zero row after them
+    const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
     const int shift_a = PT_LOWBITS, shift_b = PT_LOWBITS + 8;
     const uint32_t *n_a = c->pt_pad + 256;                 // padded length of the first pass's output, on the device
-    HIPCHK(c, hipMemsetAsync(c->pt_histA + ea - 1, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pt_histB + eb - 1, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(uint32_t), c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_histA);
-    size_t tmp = c->pt_scan_tmp_bytes;
-    HIPCHK(c, rocprim::exclusive_scan(c->pt_scan_tmp, tmp, c->pt_histA, c->pt_scanA, 0u, ea, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL(k_pt_pad, 1, 64, 0, c->stream, c->pt_scanA, ta, c->pt_pad);
-    hipLaunchKernelGGL(k_pt_zero_gaps, 256, 256, 0, c->stream, c->pt_scanA, ta, c->pt_pad, c->pt_keysA);
-    hipLaunchKernelGGL((k_pt_scatter<uint32_t>), (uint32_t)ta, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
-                       c->pt_pad, c->pt_keysA);
+    const uint64_t n_words = n / 16;
+    const int k = c->cfg.ksize;
+    uint16_t *spos_a = seeding ? nullptr : c->pt_sposA, *spos_b = seeding ? nullptr : c->pt_sposB;
+    uint8_t *sdig_a = seeding ? nullptr : c->pt_sdigA, *sdig_b = seeding ? nullptr : c->pt_sdigB;
+    if (d_keys)
+        hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_histA);
+    else if (c->cfg.canonical)
+        hipLaunchKernelGGL((k_pt_hist_words<true>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a, c->pt_histA);
+    else
+        hipLaunchKernelGGL((k_pt_hist_words<false>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a, c->pt_histA);
+    hipLaunchKernelGGL(k_pt_colsum, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks);
+    hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, ca, c->pt_totals);
+    hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 1, c->pt_pad);
+    hipLaunchKernelGGL(k_pt_rowscan, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks, c->pt_pad, c->pt_scanA);
+    hipLaunchKernelGGL(k_pt_zero_gaps, 256, 256, 0, c->stream, c->pt_totals, c->pt_pad, c->pt_keysA);
+    const uint32_t ga = (uint32_t)((ta + 7) / 8 * 8), gb = (uint32_t)((tb + 7) / 8 * 8);
+    if (d_keys)
+        hipLaunchKernelGGL((k_pt_scatter<uint32_t>), ga, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, c->pt_scanA,
+                           c->pt_keysA, spos_a, sdig_a);
+    else if (c->cfg.canonical)
+        hipLaunchKernelGGL((k_pt_scatter_words<true>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a,
+                           c->pt_scanA, c->pt_keysA, spos_a, sdig_a);
+    else
+        hipLaunchKernelGGL((k_pt_scatter_words<false>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a,
+                           c->pt_scanA, c->pt_keysA, spos_a, sdig_a);
     hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_histB);
+    hipLaunchKernelGGL(k_pt_colsum, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks);
+    hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, cb, c->pt_totals);
+    hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 0, c->pt_startB);
+    hipLaunchKernelGGL(k_pt_rowscan, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
+    hipLaunchKernelGGL((k_pt_scatter<uint16_t>), gb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, c->pt_scanB,
+                       c->pt_keysB, spos_b, sdig_b);
     HIPCHK(c, hipGetLastError());
-    tmp = c->pt_scan_tmp_bytes;
-    HIPCHK(c, rocprim::exclusive_scan(c->pt_scan_tmp, tmp, c->pt_histB, c->pt_scanB, 0u, eb, rocprim::plus<uint32_t>(), c->stream));
-    hipLaunchKernelGGL((k_pt_scatter<uint16_t>), (uint32_t)tb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
-                       (const uint32_t *)nullptr, c->pt_keysB);
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, 256, 0, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
+    hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
     hipLaunchKernelGGL(k_pt_count_bucket_big, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
-        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)tb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_scanB,
-                           (const uint32_t *)nullptr, c->pt_flagsB, c->pt_flagsA, (uint8_t)0);
-        hipLaunchKernelGGL(k_pt_gather_flags, (uint32_t)ta, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_scanA,
-                           c->pt_pad, c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW);
+        hipLaunchKernelGGL(k_pt_ungather, gb, PT_THREADS, 0, c->stream, c->pt_sposB, c->pt_sdigB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
+                           c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_pt_ungather, ga, PT_THREADS, 0, c->stream, c->pt_sposA, c->pt_sdigA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
+                           c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW, d_flags ? (uint32_t *)nullptr : c->d_wflags);
         HIPCHK(c, hipGetLastError());
     }
     if (profile) {
@@ -1590,7 +1617,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
     hipFree(c->pt_table); hipFree(c->pt_keys); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flags); hipFree(c->pt_flagsA);
     hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
-    hipFree(c->pt_scan_tmp);
+    hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB); hipFree(c->pt_sdigA); hipFree(c->pt_sdigB);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
@@ -1672,7 +1699,7 @@ int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
 {
     if (!c || !d_keys || !d_flags || (n_keys & 15)) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->partitioned) return run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, d_flags, false);
+    if (c->partitioned) return run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, 0, d_flags, false);
     return run_count(c, d_keys, n_keys, d_flags);
 }
 
@@ -1694,9 +1721,9 @@ int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_off
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->partitioned) {
         const uint64_t n_keys = (n_bases + 15) / 16 * 16;
-        if ((rc = run_kmerise(c, d_seq, d_offsets, n_reads, n_bases, c->pt_keys)) != NKML_OK) return rc;
-        if ((rc = run_count_partitioned(c, c->pt_keys, n_keys, c->pt_flags, false)) != NKML_OK) return rc;
-        if ((rc = run_reduce(c, c->pt_flags, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
+        if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+        if ((rc = run_count_partitioned(c, nullptr, n_keys, n_bases, nullptr, false)) != NKML_OK) return rc;
+        if ((rc = run_reduce_words(c, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
         if ((rc = fetch_counters(c)) != NKML_OK) return rc; // bad-base tally; the one wait of the batch
         if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
         return check_bad_bases(c);
@@ -1763,8 +1790,8 @@ int nkml_seed(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t
     int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
     if (rc != NKML_OK) return rc;
     if (c->partitioned) {
-        if ((rc = run_kmerise(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->pt_keys)) != NKML_OK) return rc;
-        if ((rc = run_count_partitioned(c, c->pt_keys, (n_bases + 15) / 16 * 16, c->pt_flags, true)) != NKML_OK) return rc;
+        if ((rc = run_prepare(c, c->d_seq, c->d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+        if ((rc = run_count_partitioned(c, nullptr, (n_bases + 15) / 16 * 16, n_bases, nullptr, true)) != NKML_OK) return rc;
         if ((rc = fetch_counters(c)) != NKML_OK) return rc;
         return check_bad_bases(c);
     }
