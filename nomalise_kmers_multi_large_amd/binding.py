@@ -47,7 +47,8 @@ class Stats(ctypes.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libnkml_hip.so")
+    # NKML_LIBRARY: another build of the same library (kernel experiments); the in-tree one otherwise
+    return os.environ.get("NKML_LIBRARY") or os.path.join(_HERE, "libnkml_hip.so")
 
 
 def load_library():

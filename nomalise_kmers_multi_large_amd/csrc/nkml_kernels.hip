@@ -1006,6 +1006,7 @@ struct nkml_ctx {
     bool partitioned;
     uint8_t *pt_table;
     uint32_t *pt_keys, *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
+    uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
     uint16_t *pt_keysB, *pt_sposA, *pt_sposB; // spos / sdig: what the forward passes leave for the reverse passes
     uint8_t *pt_sdigA, *pt_sdigB;
@@ -1118,6 +1119,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_scanB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_startB, 260 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_tally, ((c->capacity >> PT_LOWBITS) + 1) * sizeof(uint4)));
         HIPCHK(c, hipMalloc(&c->pt_totals, 256 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_chunks, 256 * ((c->pt_tiles_b + 1 + PT_CH - 1) / PT_CH + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -1440,18 +1442,23 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
-                       (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+                       (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
+    hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
+
     hipLaunchKernelGGL(k_pt_count_bucket_big, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
-        hipLaunchKernelGGL(k_pt_ungather, gb, PT_THREADS, 0, c->stream, c->pt_sposB, c->pt_sdigB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
+        hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, c->pt_sdigB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
                            c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_pt_ungather, ga, PT_THREADS, 0, c->stream, c->pt_sposA, c->pt_sdigA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
+        hipLaunchKernelGGL(k_pt_ungather, ga, PU_THREADS, 0, c->stream, c->pt_sposA, c->pt_sdigA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
                            c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW, d_flags ? (uint32_t *)nullptr : c->d_wflags);
         HIPCHK(c, hipGetLastError());
     }
+#ifdef PB_STAMP
+    hipLaunchKernelGGL(k_pt_stamp_print, 1, 1, 0, c->stream, (uint32_t)buckets);
+#endif
     if (profile) {
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->pt_timed_keys = n;
@@ -1617,7 +1624,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
     hipFree(c->pt_table); hipFree(c->pt_keys); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flags); hipFree(c->pt_flagsA);
     hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
-    hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB); hipFree(c->pt_sdigA); hipFree(c->pt_sdigB);
+    hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB); hipFree(c->pt_sdigA); hipFree(c->pt_sdigB);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
