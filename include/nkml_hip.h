@@ -67,6 +67,12 @@ typedef struct nkml_config {
 #define NKML_F_EXACT_COUNTS 2u /* keep counting k-mers after they reach depth (only nkml_dump_table can tell: --print,
                                   ref:354-385); costs one more atomic per saturated occurrence and, for k <= 16,
                                   a second 4^k-entry counter array */
+#define NKML_F_COUNT_ATOMIC 4u /* count with atomics on the table even where the partitioned path would be chosen */
+#define NKML_F_COUNT_PARTITIONED 8u /* count by radix-partitioning each batch's k-mers into 2^14-code buckets that are
+                                  counted in LDS against a 1-byte-per-k-mer table, wherever that path can run
+                                  (k <= 15, depth <= 127, no NKML_F_EXACT_COUNTS).  With neither flag the library
+                                  chooses: partitioned at k = 15, atomics otherwise; the environment variable
+                                  NKML_PARTITIONED=0/1 overrides that choice.  Results are identical either way. */
 
 typedef struct nkml_stats {
     uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */

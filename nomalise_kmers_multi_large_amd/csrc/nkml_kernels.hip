@@ -1550,8 +1550,15 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     c->cfg = *cfg;
     c->direct = cfg->ksize <= 16;
     {
+        // the partitioned path needs 30-bit codes, 7-bit saturating counts and no exact counts past depth; it pays
+        // where a batch spreads over many 2^14-code buckets, i.e. at k = 15 (4^15 / 2^14 = 65536 buckets)
+        const bool can = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS);
         const char *env = getenv("NKML_PARTITIONED");
-        c->partitioned = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS) && env && env[0] == '1';
+        bool want = cfg->ksize == 15;
+        if (env && (env[0] == '0' || env[0] == '1')) want = env[0] == '1';
+        if (cfg->flags & NKML_F_COUNT_PARTITIONED) want = true;
+        if (cfg->flags & NKML_F_COUNT_ATOMIC) want = false;
+        c->partitioned = can && want;
     }
     c->key_bytes = c->direct ? 4 : 8;
     uint32_t chunk = cfg->chunk_bases ? cfg->chunk_bases : (32u << 20);

@@ -302,7 +302,8 @@ def test_partitioned_random_reads(nk, oracle_lib, k, depth, canonical):
         np.testing.assert_array_equal(total, [w[2] for w in want])
         assert g.unique_kmers == o.unique
         st = g.stats()
-        assert st["kmers_counted"] == int(total.sum()) and st["crossing_kmers"] == 0  # no atomic-path bookkeeping ran
+        assert st["kmers_counted"] == int(total.sum())
+        assert st["table_bytes"] == st["capacity"]  # the one-byte-per-k-mer table: the partitioned path is the one that ran
 
 
 @pytest.mark.parametrize("on", [False, True])
