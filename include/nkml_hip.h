@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NKML_ABI_VERSION 1
+#define NKML_ABI_VERSION 2
 
 enum {
     NKML_OK = 0,
@@ -83,9 +83,13 @@ typedef struct nkml_stats {
     uint64_t crossing_kmers;   /* k-mers whose count reached depth so far */
     uint64_t crossing_occurrences; /* occurrences that needed exact stream-order ranking */
     uint64_t resizes;          /* hashed table growth events (expand_local_hash_table, ref:1055-1108) */
-    double count_kernel_ms;    /* NKML_F_PROFILE: summed duration of the counting kernel's launches */
+    double count_kernel_ms;    /* NKML_F_PROFILE: summed duration of the counting kernel's launches (atomic path: the
+                                  kernel that counts a chunk of positions; partitioned path: the bucket-counting kernel) */
     uint64_t count_kernel_launches;
     uint64_t count_kernel_keys;    /* window positions those launches covered */
+    double count_stage_ms;     /* NKML_F_PROFILE, partitioned path: summed duration of the whole counting stage of each
+                                  batch (histograms, partition passes, bucket counting, the flags' way back); else 0 */
+    uint64_t partitioned;      /* 1 if this context counts by partitioning (NKML_F_COUNT_PARTITIONED), 0 if with atomics */
 } nkml_stats;
 
 /* Library/ABI probes (no GPU needed). */

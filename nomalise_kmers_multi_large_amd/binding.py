@@ -40,7 +40,8 @@ class Stats(ctypes.Structure):
                 ("kmers_counted", ctypes.c_uint64), ("kmers_saturated", ctypes.c_uint64),
                 ("crossing_kmers", ctypes.c_uint64), ("crossing_occurrences", ctypes.c_uint64),
                 ("resizes", ctypes.c_uint64), ("count_kernel_ms", ctypes.c_double),
-                ("count_kernel_launches", ctypes.c_uint64), ("count_kernel_keys", ctypes.c_uint64)]
+                ("count_kernel_launches", ctypes.c_uint64), ("count_kernel_keys", ctypes.c_uint64),
+                ("count_stage_ms", ctypes.c_double), ("partitioned", ctypes.c_uint64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

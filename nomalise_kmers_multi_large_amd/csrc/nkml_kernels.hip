@@ -1014,7 +1014,7 @@ struct nkml_ctx {
     uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
     uint64_t pt_timed_keys;
     bool pt_timing_pending;
-    double pt_bucket_ms;
+    double pt_stage_ms;
     Slot *slots;            // hashed
     uint64_t capacity;      // slots / counters
     uint64_t resizes;
@@ -1156,6 +1156,7 @@ int clear_table(nkml_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->crossing_kmers = c->crossing_occ = 0;
     c->count_ms = 0;
+    c->pt_stage_ms = 0;
     c->count_launches = c->count_keys = 0;
     return NKML_OK;
 }
@@ -1443,11 +1444,11 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
 
     hipLaunchKernelGGL(k_pt_count_bucket_big, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
-    if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
         hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, c->pt_sdigB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
@@ -1475,8 +1476,8 @@ int collect_partition_timing(nkml_ctx *c)
     float whole = 0, bucket = 0;
     HIPCHK(c, hipEventElapsedTime(&whole, c->ev[0], c->ev[1]));
     HIPCHK(c, hipEventElapsedTime(&bucket, c->ev[2], c->ev[3]));
-    c->count_ms += whole;
-    c->pt_bucket_ms += bucket;
+    c->count_ms += bucket;
+    c->pt_stage_ms += whole;
     c->count_launches++;
     c->count_keys += c->pt_timed_keys;
     c->pt_timing_pending = false;
@@ -1695,6 +1696,8 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     out->count_kernel_ms = c->count_ms;
     out->count_kernel_launches = c->count_launches;
     out->count_kernel_keys = c->count_keys;
+    out->count_stage_ms = c->pt_stage_ms;
+    out->partitioned = c->partitioned ? 1 : 0;
     return NKML_OK;
 }
 
