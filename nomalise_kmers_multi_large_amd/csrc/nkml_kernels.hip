@@ -1391,6 +1391,8 @@ int run_reduce(nkml_ctx *c, const uint8_t *d_flags, const uint64_t *d_offsets, u
 
 // Partitioned counting of a key array (k <= 15): two stable radix passes, one workgroup per bucket, two reverse
 // passes for the flags.  Nothing here waits for the device.
+int collect_partition_timing(nkml_ctx *c);
+
 // d_keys == nullptr: the keys of the first pass are recomputed from the context's packed words (n_bases of them
 // prepared); d_flags == nullptr: the result is the context's word flags (one word per 16 positions).
 int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
@@ -1398,6 +1400,10 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     if (n == 0) return NKML_OK;
     if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
+    if (profile && c->pt_timing_pending) { // the events are about to be recorded again: read the last batch's first
+        int rc = collect_partition_timing(c);
+        if (rc != NKML_OK) return rc;
+    }
     const uint64_t ta = (n + PT_TILE - 1) / PT_TILE;       // first-pass tiles of this batch
     const uint64_t tb = ta + 256 + 1;                      // bound on second-pass tiles (each group padded to a tile)
     const uint64_t ra = ta + 1, rb = tb + 1;               // histogram rows: the tiles and the all-zero row after them
@@ -1675,7 +1681,7 @@ int nkml_synchronize(nkml_ctx *c)
 {
     if (!c) return NKML_E_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return NKML_OK;
+    return collect_partition_timing(c);
 }
 
 int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
@@ -1684,6 +1690,7 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc = fetch_counters(c);
     if (rc != NKML_OK) return rc;
+    if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
     memset(out, 0, sizeof *out);
     out->unique_kmers = c->h_ctr->unique;
     out->capacity = c->capacity;
