@@ -115,6 +115,10 @@ int nkml_get_stats(nkml_ctx *ctx, nkml_stats *out);
  * per-read counters in submission order.  Batch form of process_sequence_pair/_single (ref:1551, 1539). */
 int nkml_submit(nkml_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
 int nkml_collect(nkml_ctx *ctx, int32_t *high, int32_t *total);
+/* The context's own pinned staging area (max_batch_bases bytes, max_batch_reads + 1 offsets): a caller that
+ * builds its batch there and passes these pointers to nkml_submit / nkml_seed saves one copy of the batch.
+ * No counterpart in the reference (its records are counted where read_line left them, ref:1605-1629). */
+int nkml_host_staging(nkml_ctx *ctx, uint8_t **seq, uint64_t **offsets);
 
 /* Device-buffer path: the same batch already resident in HBM; d_high/d_total are device arrays of n_reads.
  * Asynchronous on the context's stream. */

@@ -1771,11 +1771,19 @@ static int stage_host_batch(nkml_ctx *c, const uint8_t *seq, const uint64_t *off
             return fail(c, NKML_E_ARG, "read %u is shorter than k=%d (the caller drops such records)", i, k);
     }
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    memcpy(c->h_seq, seq, n_bases);
-    memcpy(c->h_offsets, offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t));
+    if (seq != c->h_seq) memcpy(c->h_seq, seq, n_bases);
+    if (offsets != c->h_offsets) memcpy(c->h_offsets, offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t));
     HIPCHK(c, hipMemcpyAsync(c->d_seq, c->h_seq, n_bases, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_offsets, c->h_offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     *n_bases_out = n_bases;
+    return NKML_OK;
+}
+
+int nkml_host_staging(nkml_ctx *c, uint8_t **seq, uint64_t **offsets)
+{
+    if (!c || !seq || !offsets) return NKML_E_ARG;
+    *seq = c->h_seq;
+    *offsets = c->h_offsets;
     return NKML_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <fcntl.h>
 #include <getopt.h>
 #include <locale.h>
+#include <pthread.h>
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -273,19 +274,130 @@ static void fatal_sequence(const char *which, const char *s, uint32_t n)
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
-/* One batch in flight: staged sequence bytes + where each unit's record(s) start in the mmap'd files. */
+/* Host threads.  The record loop is a sequence of data-parallel phases over one window of the input files
+ * (index the lines, size and stage the records, [GPU], format the kept records), each run on n_threads threads. */
+#define MAX_THREADS 64
+static int n_threads = 1;
+typedef void (*par_fn)(int tid, int nt, void *arg);
+struct par_call { par_fn fn; void *arg; int tid, nt; };
+static void *par_tramp(void *p)
+{
+    struct par_call *c = p;
+    c->fn(c->tid, c->nt, c->arg);
+    return NULL;
+}
+static void parallel_run(par_fn fn, void *arg)
+{
+    pthread_t th[MAX_THREADS];
+    struct par_call pc[MAX_THREADS];
+    const int nt = n_threads;
+    for (int t = 1; t < nt; t++) {
+        pc[t] = (struct par_call){fn, arg, t, nt};
+        if (pthread_create(&th[t], NULL, par_tramp, &pc[t]) != 0) { perror("pthread_create"); exit(EXIT_FAILURE); }
+    }
+    fn(0, nt, arg);
+    for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+}
+
+/* Line index of one window of a file: nl[g] = offset of the newline that ends line g. */
+struct findex {
+    const char *base;
+    size_t size;
+    uint32_t *nl;
+    size_t n_nl, cap_nl;
+    size_t n_lines; /* newline-terminated lines, plus the unterminated last line of the file (ref:394-409) */
+    size_t cnt[MAX_THREADS + 1];
+};
+static inline size_t line_start(const struct findex *fi, size_t g) { return g ? (size_t)fi->nl[g - 1] + 1 : 0; }
+static inline size_t line_end(const struct findex *fi, size_t g) { return g < fi->n_nl ? (size_t)fi->nl[g] : fi->size; }
+
+static void index_count(int tid, int nt, void *arg)
+{
+    struct findex *fi = arg;
+    const char *p = fi->base + fi->size * (size_t)tid / (size_t)nt, *e = fi->base + fi->size * (size_t)(tid + 1) / (size_t)nt;
+    size_t c = 0;
+    while (p < e) {
+        const char *q = memchr(p, '\n', (size_t)(e - p));
+        if (!q) break;
+        c++;
+        p = q + 1;
+    }
+    fi->cnt[tid] = c;
+}
+static void index_fill(int tid, int nt, void *arg)
+{
+    struct findex *fi = arg;
+    const char *p = fi->base + fi->size * (size_t)tid / (size_t)nt, *e = fi->base + fi->size * (size_t)(tid + 1) / (size_t)nt;
+    size_t at = 0;
+    for (int t = 0; t < tid; t++) at += fi->cnt[t];
+    while (p < e) {
+        const char *q = memchr(p, '\n', (size_t)(e - p));
+        if (!q) break;
+        fi->nl[at++] = (uint32_t)(q - fi->base);
+        p = q + 1;
+    }
+}
+static void build_index(struct findex *fi, const char *base, size_t size, bool at_eof)
+{
+    fi->base = base;
+    fi->size = size;
+    parallel_run(index_count, fi);
+    size_t n = 0;
+    for (int t = 0; t < n_threads; t++) n += fi->cnt[t];
+    if (n > fi->cap_nl) {
+        free(fi->nl);
+        fi->cap_nl = n + n / 8 + 1024;
+        fi->nl = malloc(fi->cap_nl * sizeof(uint32_t));
+        if (!fi->nl) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    }
+    fi->n_nl = n;
+    parallel_run(index_fill, fi);
+    fi->n_lines = n + (at_eof && size > 0 && base[size - 1] != '\n' ? 1 : 0);
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* One batch in flight: the records of one window, their sequence lines staged in the library's pinned area. */
 struct batch {
-    uint8_t *seq;
+    uint8_t *seq;       /* pinned staging of the library (nkml_host_staging) */
     uint64_t *offsets;
-    const char **rec_fwd, **rec_rev; /* per unit (pair or single read) */
+    uint32_t *rec;      /* per unit (pair or single read): its record number in the window */
     int32_t *high, *total;
+    uint8_t *use;       /* per record of the window: long enough to be counted (ref:1630-1631) */
     uint32_t n_reads, n_units;
     uint64_t n_bases;
     uint32_t cap_reads;
     uint64_t cap_bases;
+    size_t cap_use;
+};
+
+struct plan {
+    struct findex F, R;
+    bool paired, to_fasta;
+    int lines;
+    uint32_t K;
+    size_t n_rec;
+    /* sizing pass, per thread */
+    size_t t_units[MAX_THREADS], t_bases[MAX_THREADS], t_bad[MAX_THREADS];
+    int t_bad_rev[MAX_THREADS], long_line;
+    /* formatting pass, per thread */
+    char *obuf[2][MAX_THREADS];
+    size_t ocap[2][MAX_THREADS], olen[2][MAX_THREADS], t_printed[MAX_THREADS];
 };
 
 static struct batch B;
+static struct plan P;
+
+/* NKML_TIMING=1: wall time of each phase of the host pipeline on stderr at exit */
+static int timing_on;
+static double t_phase[8];
+static const char *t_name[8] = {"index", "size", "stage", "gpu", "format", "write", "seed", "setup"};
+static inline double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#define TIMED(slot, stmt) do { double t0_ = timing_on ? now_s() : 0; stmt; if (timing_on) t_phase[slot] += now_s() - t0_; } while (0)
 static nkml_ctx *ctx;
 static FILE *out_fwd, *out_rev;
 static struct totals tot;
@@ -301,13 +413,12 @@ static void batch_alloc(uint32_t cap_reads, uint64_t cap_bases)
 {
     B.cap_reads = cap_reads;
     B.cap_bases = cap_bases;
-    B.seq = malloc(cap_bases);
-    B.offsets = malloc(((size_t)cap_reads + 1) * sizeof(uint64_t));
-    B.rec_fwd = malloc((size_t)cap_reads * sizeof(char *));
-    B.rec_rev = malloc((size_t)cap_reads * sizeof(char *));
+    int rc = nkml_host_staging(ctx, &B.seq, &B.offsets);
+    if (rc != NKML_OK) die_nkml("staging", rc);
+    B.rec = malloc((size_t)cap_reads * sizeof(uint32_t));
     B.high = malloc((size_t)cap_reads * sizeof(int32_t));
     B.total = malloc((size_t)cap_reads * sizeof(int32_t));
-    if (!B.seq || !B.offsets || !B.rec_fwd || !B.rec_rev || !B.high || !B.total) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    if (!B.rec || !B.high || !B.total) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
     B.offsets[0] = 0;
 }
 
@@ -318,127 +429,279 @@ static inline void stage_read(const char *s, uint32_t n)
     B.offsets[++B.n_reads] = B.n_bases;
 }
 
-static void write_line_masked(FILE *f, const char *s, uint32_t n)
-{
-    if (memchr(s, 'N', n)) {
-        char buf[MAX_LINE + 1];
-        for (uint32_t i = 0; i < n; i++) buf[i] = s[i] == 'N' ? 'A' : s[i];
-        fwrite(buf, 1, n, f);
-    } else {
-        fwrite(s, 1, n, f);
-    }
-    fputc('\n', f);
-}
-
-/* Kept record, ref:1649-1666: the stored lines with the sequence line N-masked, or the FASTQ->FASTA form
- * (ref:852-876: '>' header, "/1" or "/2" appended unless the header already ends with it). */
-static void write_record(FILE *f, const char *rec, const char *end, int lines, bool to_fasta, bool is_forward)
-{
-    const char *start[4];
-    uint32_t len[4];
-    frame_record(rec, end, lines, start, len);
-    if (to_fasta) {
-        const char *suffix = is_forward ? "/1" : "/2";
-        fputc('>', f);
-        if (len[0] > 1) fwrite(start[0] + 1, 1, len[0] - 1, f);
-        if (len[0] < 2 || memcmp(start[0] + len[0] - 2, suffix, 2) != 0) fwrite(suffix, 1, 2, f);
-        fputc('\n', f);
-        write_line_masked(f, start[1], len[1]);
-        return;
-    }
-    for (int i = 0; i < lines; i++) {
-        if (i == 1) write_line_masked(f, start[i], len[i]);
-        else { fwrite(start[i], 1, len[i], f); fputc('\n', f); }
-    }
-}
-
 static inline float ratio_f32(int32_t high, int32_t total)
 {
     volatile float r = total > 0 ? (float)high / (float)total : 0.0f; /* ref:1641 */
     return r;
 }
 
-/* Count the staged batch on the GPU, then decide and write in input order. */
-static void flush_batch(bool paired, const char *end_fwd, const char *end_rev, int lines)
+static inline void rec_range(size_t n, int tid, int nt, size_t *a, size_t *b)
 {
-    if (B.n_units == 0) return;
-    int rc = nkml_submit(ctx, B.seq, B.offsets, B.n_reads);
-    if (rc != NKML_OK) die_nkml("submit", rc);
-    rc = nkml_collect(ctx, B.high, B.total);
-    if (rc != NKML_OK) die_nkml("collect", rc);
-    const bool to_fasta = cfg.fastq_in && !cfg.fastq_out;
-    for (uint32_t u = 0; u < B.n_units; u++) {
-        bool keep;
-        tot.processed++;
-        if (paired) {
-            int32_t hf = B.high[2 * u], tf = B.total[2 * u], hr = B.high[2 * u + 1], tr = B.total[2 * u + 1];
-            keep = nkml_keep_pair(hf, tf, hr, tr, cfg.coverage) != 0; /* ref:1646 */
-            if (keep) {
-                write_record(out_fwd, B.rec_fwd[u], end_fwd, lines, to_fasta, true);
-                write_record(out_rev, B.rec_rev[u], end_rev, lines, to_fasta, false);
-                tot.printed++;
-            } else {
-                tot.skipped++;
-            }
-            if (cfg.debug > 1) /* ref:1677-1692 */
-                printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d;R:%d, Total kmers: F:%d;R:%d High count ratio: F:%.2f;R:%.2f\n",
-                       tot.processed, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, hr, tf, tr, ratio_f32(hf, tf), ratio_f32(hr, tr));
+    *a = n * (size_t)tid / (size_t)nt;
+    *b = n * (size_t)(tid + 1) / (size_t)nt;
+}
+
+/* sequence line (line 1) of record i */
+static inline const char *seq_line(const struct findex *fi, int lines, size_t i, uint32_t *len)
+{
+    const size_t g = i * (size_t)lines + 1, a = line_start(fi, g);
+    *len = (uint32_t)(line_end(fi, g) - a);
+    return fi->base + a;
+}
+
+/* Phase 1: is_valid_sequence_pair / _single (ref:1404-1457) for every record: lengths first, then the alphabet.
+ * Each thread stops at its first record with a bad base; records after the first such record of the window are
+ * not processed at all (the reference exits there). */
+static void size_records(int tid, int nt, void *arg)
+{
+    (void)arg;
+    size_t a, b;
+    rec_range(P.n_rec, tid, nt, &a, &b);
+    size_t units = 0, bases = 0;
+    P.t_bad[tid] = SIZE_MAX;
+    for (size_t i = a; i < b; i++) {
+        for (int l = 0; l < P.lines; l++) {
+            const size_t g = i * (size_t)P.lines + (size_t)l;
+            if (line_end(&P.F, g) - line_start(&P.F, g) > MAX_LINE) P.long_line = 1;
+            if (P.paired && line_end(&P.R, g) - line_start(&P.R, g) > MAX_LINE) P.long_line = 1;
+        }
+        uint32_t lf, lr = 0;
+        const char *sf = seq_line(&P.F, P.lines, i, &lf);
+        const char *sr = P.paired ? seq_line(&P.R, P.lines, i, &lr) : NULL;
+        const bool long_enough = lf >= P.K && (!P.paired || lr >= P.K);
+        B.use[i] = long_enough;
+        if (!long_enough) continue; /* dropped without being counted anywhere, ref:1630-1631 */
+        if (lf > MAX_LINE || lr > MAX_LINE) continue; /* reported after the phase */
+        if (!valid_bases(sf, lf)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 0; break; }
+        if (P.paired && !valid_bases(sr, lr)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 1; break; }
+        units++;
+        bases += (size_t)lf + lr;
+    }
+    P.t_units[tid] = units;
+    P.t_bases[tid] = bases;
+}
+
+/* Phase 2: sequence lines into the staging area, in record order */
+static void stage_records(int tid, int nt, void *arg)
+{
+    (void)arg;
+    size_t a, b;
+    rec_range(P.n_rec, tid, nt, &a, &b);
+    size_t u = 0, at = 0;
+    for (int t = 0; t < tid; t++) { u += P.t_units[t]; at += P.t_bases[t]; }
+    const size_t u_end = u + P.t_units[tid];
+    for (size_t i = a; i < b && u < u_end; i++) {
+        if (!B.use[i]) continue;
+        uint32_t lf, lr = 0;
+        const char *sf = seq_line(&P.F, P.lines, i, &lf);
+        B.rec[u] = (uint32_t)i;
+        if (P.paired) {
+            const char *sr = seq_line(&P.R, P.lines, i, &lr);
+            memcpy(B.seq + at, sf, lf);
+            B.offsets[2 * u + 1] = at + lf;
+            memcpy(B.seq + at + lf, sr, lr);
+            B.offsets[2 * u + 2] = at + lf + lr;
         } else {
-            int32_t hf = B.high[u], tf = B.total[u];
-            keep = nkml_keep_single(hf, tf, cfg.coverage) != 0; /* ref:1992 */
-            if (keep) {
-                /* ref:1995-1999: the single-end FASTQ->FASTA branch builds the record and never writes it */
-                if (!to_fasta) write_record(out_fwd, B.rec_fwd[u], end_fwd, lines, false, true);
-                tot.printed++;
-            } else {
-                tot.skipped++;
-            }
-            if (cfg.debug > 1) /* ref:2017-2032 */
-                printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d, Total kmers: F:%d High count ratio: F:%.2f\n",
-                       tot.processed, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, tf, ratio_f32(hf, tf));
+            memcpy(B.seq + at, sf, lf);
+            B.offsets[u + 1] = at + lf;
+        }
+        at += (size_t)lf + lr;
+        u++;
+    }
+}
+
+static inline char *put_masked(char *o, const char *s, size_t n)
+{
+    memcpy(o, s, n);
+    if (memchr(s, 'N', n))
+        for (size_t i = 0; i < n; i++)
+            if (o[i] == 'N') o[i] = 'A';
+    o[n] = '\n';
+    return o + n + 1;
+}
+
+/* Kept record, ref:1649-1666: the stored lines with the sequence line N-masked, or the FASTQ->FASTA form
+ * (ref:852-876: '>' header, "/1" or "/2" appended unless the header already ends with it). */
+static char *put_record(char *o, const struct findex *fi, size_t i, int lines, bool to_fasta, bool is_forward)
+{
+    const size_t g0 = i * (size_t)lines;
+    if (to_fasta) {
+        const char *h = fi->base + line_start(fi, g0);
+        const size_t hl = line_end(fi, g0) - line_start(fi, g0);
+        const char *suffix = is_forward ? "/1" : "/2";
+        *o++ = '>';
+        if (hl > 1) { memcpy(o, h + 1, hl - 1); o += hl - 1; }
+        if (hl < 2 || memcmp(h + hl - 2, suffix, 2) != 0) { memcpy(o, suffix, 2); o += 2; }
+        *o++ = '\n';
+        return put_masked(o, fi->base + line_start(fi, g0 + 1), line_end(fi, g0 + 1) - line_start(fi, g0 + 1));
+    }
+    for (int l = 0; l < lines; l++) {
+        const size_t a = line_start(fi, g0 + (size_t)l), n = line_end(fi, g0 + (size_t)l) - a;
+        if (l == 1) o = put_masked(o, fi->base + a, n);
+        else { memcpy(o, fi->base + a, n); o[n] = '\n'; o += n + 1; }
+    }
+    return o;
+}
+
+static inline bool keep_unit(uint32_t u)
+{
+    if (P.paired) return nkml_keep_pair(B.high[2 * u], B.total[2 * u], B.high[2 * u + 1], B.total[2 * u + 1], cfg.coverage) != 0; /* ref:1646 */
+    return nkml_keep_single(B.high[u], B.total[u], cfg.coverage) != 0;                                                             /* ref:1992 */
+}
+
+/* Phase 3: decisions and the bytes of the kept records, per thread into its own buffer (written out in thread order) */
+static void format_records(int tid, int nt, void *arg)
+{
+    (void)arg;
+    size_t a, b;
+    rec_range(B.n_units, tid, nt, &a, &b);
+    P.olen[0][tid] = P.olen[1][tid] = 0;
+    P.t_printed[tid] = 0;
+    if (a == b) return;
+    /* ref:1995-1999: the single-end FASTQ->FASTA branch builds the record and never writes it */
+    const bool write_f = P.paired || !P.to_fasta, write_r = P.paired;
+    for (int f = 0; f < 2; f++) {
+        if (!(f == 0 ? write_f : write_r)) continue;
+        const struct findex *fi = f == 0 ? &P.F : &P.R;
+        const size_t first = (size_t)B.rec[a] * (size_t)P.lines, last = (size_t)B.rec[b - 1] * (size_t)P.lines + (size_t)P.lines - 1;
+        const size_t need = line_end(fi, last) - line_start(fi, first) + 4 * (b - a) + 64;
+        if (need > P.ocap[f][tid]) {
+            free(P.obuf[f][tid]);
+            P.ocap[f][tid] = need + need / 4;
+            P.obuf[f][tid] = malloc(P.ocap[f][tid]);
+            if (!P.obuf[f][tid]) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
         }
     }
+    char *of = P.obuf[0][tid], *orv = P.obuf[1][tid];
+    size_t printed = 0;
+    for (size_t u = a; u < b; u++) {
+        if (!keep_unit((uint32_t)u)) continue;
+        printed++;
+        if (write_f) of = put_record(of, &P.F, B.rec[u], P.lines, P.to_fasta, true);
+        if (write_r) orv = put_record(orv, &P.R, B.rec[u], P.lines, P.to_fasta, false);
+    }
+    P.olen[0][tid] = write_f ? (size_t)(of - P.obuf[0][tid]) : 0;
+    P.olen[1][tid] = write_r ? (size_t)(orv - P.obuf[1][tid]) : 0;
+    P.t_printed[tid] = printed;
+}
+
+/* Count the staged batch on the GPU, then decide and write in input order. */
+static void flush_batch(void)
+{
+    if (B.n_units == 0) return;
+    int rc = 0;
+    TIMED(3, {
+        rc = nkml_submit(ctx, B.seq, B.offsets, B.n_reads);
+        if (rc != NKML_OK) die_nkml("submit", rc);
+        rc = nkml_collect(ctx, B.high, B.total);
+        if (rc != NKML_OK) die_nkml("collect", rc);
+    });
+    TIMED(4, parallel_run(format_records, NULL));
+    TIMED(5, {
+        for (int t = 0; t < n_threads; t++) {
+            if (P.olen[0][t]) fwrite(P.obuf[0][t], 1, P.olen[0][t], out_fwd);
+            if (P.olen[1][t]) fwrite(P.obuf[1][t], 1, P.olen[1][t], out_rev);
+        }
+    });
+    if (cfg.debug > 1) {
+        for (uint32_t u = 0; u < B.n_units; u++) {
+            const bool keep = keep_unit(u);
+            if (P.paired) { /* ref:1677-1692 */
+                int32_t hf = B.high[2 * u], tf = B.total[2 * u], hr = B.high[2 * u + 1], tr = B.total[2 * u + 1];
+                printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d;R:%d, Total kmers: F:%d;R:%d High count ratio: F:%.2f;R:%.2f\n",
+                       tot.processed + u + 1, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, hr, tf, tr, ratio_f32(hf, tf), ratio_f32(hr, tr));
+            } else { /* ref:2017-2032 */
+                int32_t hf = B.high[u], tf = B.total[u];
+                printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d, Total kmers: F:%d High count ratio: F:%.2f\n",
+                       tot.processed + u + 1, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, tf, ratio_f32(hf, tf));
+            }
+        }
+    }
+    size_t printed = 0;
+    for (int t = 0; t < n_threads; t++) printed += P.t_printed[t];
+    tot.processed += B.n_units;
+    tot.printed += printed;
+    tot.skipped += B.n_units - printed;
     B.n_reads = B.n_units = 0;
     B.n_bases = 0;
 }
 
-/* The record loop of process_thread_chunk_paired / _single (ref:1568-1770, 1921-2111) for one file (pair). */
+/* The record loop of process_thread_chunk_paired / _single (ref:1568-1770, 1921-2111) for one file (pair):
+ * window after window, each a whole number of records that fits one GPU batch. */
 static void process_files(const struct mapped *fwd, const struct mapped *rev)
 {
-    const int lines = cfg.fastq_in ? 4 : 2;
-    const bool paired = rev != NULL;
-    const char *pf = fwd->data, *ef = fwd->data + fwd->size;
-    const char *pr = paired ? rev->data : NULL, *er = paired ? rev->data + rev->size : NULL;
-    const uint32_t K = (uint32_t)cfg.ksize;
-    const char *sf[4], *sr[4];
-    uint32_t lf[4], lr[4];
+    P.lines = cfg.fastq_in ? 4 : 2;
+    P.paired = rev != NULL;
+    P.to_fasta = cfg.fastq_in && !cfg.fastq_out;
+    P.K = (uint32_t)cfg.ksize;
+    const size_t cap_units = P.paired ? B.cap_reads / 2 : B.cap_reads;
+    size_t pos_f = 0, pos_r = 0;
+    size_t bytes_per_rec = 512; /* window size guess; follows the data */
     for (;;) {
-        const char *nf = frame_record(pf, ef, lines, sf, lf);
-        if (!nf) break;
-        const char *nr = NULL;
-        if (paired) {
-            nr = frame_record(pr, er, lines, sr, lr);
-            if (!nr) break;
+        size_t want = cap_units * bytes_per_rec;
+        if (want > (size_t)3 << 30) want = (size_t)3 << 30; /* line offsets are 32-bit */
+        size_t wf = fwd->size - pos_f < want ? fwd->size - pos_f : want;
+        TIMED(0, build_index(&P.F, fwd->data + pos_f, wf, pos_f + wf == fwd->size));
+        size_t n_rec = P.F.n_lines / (size_t)P.lines;
+        size_t wr = 0;
+        if (P.paired) {
+            wr = rev->size - pos_r < want ? rev->size - pos_r : want;
+            TIMED(0, build_index(&P.R, rev->data + pos_r, wr, pos_r + wr == rev->size));
+            if (P.R.n_lines / (size_t)P.lines < n_rec) n_rec = P.R.n_lines / (size_t)P.lines;
         }
-        /* is_valid_sequence_pair / _single, ref:1404-1457: lengths first, then the alphabet */
-        bool long_enough = lf[1] >= K && (!paired || lr[1] >= K);
-        if (long_enough) {
-            if (!valid_bases(sf[1], lf[1])) { flush_batch(paired, ef, er, lines); fatal_sequence("FWD", sf[1], lf[1]); exit(EXIT_FAILURE); }
-            if (paired && !valid_bases(sr[1], lr[1])) { flush_batch(paired, ef, er, lines); fatal_sequence("REV", sr[1], lr[1]); exit(EXIT_FAILURE); }
-            uint64_t need = (uint64_t)lf[1] + (paired ? lr[1] : 0);
-            if (B.n_reads + 2 > B.cap_reads || B.n_bases + need > B.cap_bases) flush_batch(paired, ef, er, lines);
-            B.rec_fwd[B.n_units] = pf;
-            stage_read(sf[1], lf[1]);
-            if (paired) {
-                B.rec_rev[B.n_units] = pr;
-                stage_read(sr[1], lr[1]);
+        if (n_rec > cap_units) n_rec = cap_units;
+        if (n_rec == 0) break; /* fewer lines left than one record (pair): the loop of ref:1605 ends */
+        if (n_rec > B.cap_use) {
+            free(B.use);
+            B.cap_use = n_rec + n_rec / 8;
+            B.use = malloc(B.cap_use);
+            if (!B.use) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+        }
+        size_t bad = SIZE_MAX;
+        int bad_rev = 0;
+        for (;;) {
+            P.n_rec = n_rec;
+            P.long_line = 0;
+            TIMED(1, parallel_run(size_records, NULL));
+            if (P.long_line) {
+                fprintf(stderr, "FATAL: input line longer than %d bytes\n", MAX_LINE);
+                exit(EXIT_FAILURE);
             }
-            B.n_units++;
-        } /* else: the record is dropped without being counted anywhere, ref:1630-1631 */
-        pf = nf;
-        if (paired) pr = nr;
+            bad = SIZE_MAX;
+            for (int t = 0; t < n_threads; t++)
+                if (P.t_bad[t] < bad) { bad = P.t_bad[t]; bad_rev = P.t_bad_rev[t]; }
+            size_t units = 0, bases = 0;
+            for (int t = 0; t < n_threads; t++) {
+                size_t a, b;
+                rec_range(n_rec, t, n_threads, &a, &b);
+                if (a > bad) P.t_units[t] = P.t_bases[t] = 0; /* beyond the record the run stops at */
+                units += P.t_units[t];
+                bases += P.t_bases[t];
+            }
+            if (bases <= B.cap_bases) { B.n_units = (uint32_t)units; B.n_bases = bases; break; }
+            n_rec = (size_t)((double)n_rec * (double)B.cap_bases / (double)bases * 0.98); /* too many bases for one batch */
+            if (n_rec == 0) n_rec = 1;
+        }
+        B.n_reads = P.paired ? 2 * B.n_units : B.n_units;
+        TIMED(2, parallel_run(stage_records, NULL));
+        flush_batch();
+        if (bad != SIZE_MAX) {
+            uint32_t len;
+            const char *sq = seq_line(bad_rev ? &P.R : &P.F, P.lines, bad, &len);
+            fatal_sequence(bad_rev ? "REV" : "FWD", sq, len);
+            exit(EXIT_FAILURE);
+        }
+        /* on to the byte after the last record taken */
+        const size_t last = n_rec * (size_t)P.lines - 1;
+        const size_t used_f = line_end(&P.F, last) + (last < P.F.n_nl ? 1 : 0);
+        pos_f += used_f;
+        bytes_per_rec = used_f / n_rec + 64;
+        if (P.paired) {
+            const size_t used_r = line_end(&P.R, last) + (last < P.R.n_nl ? 1 : 0);
+            pos_r += used_r;
+            if (used_r / n_rec + 64 > bytes_per_rec) bytes_per_rec = used_r / n_rec + 64;
+        }
     }
-    flush_batch(paired, ef, er, lines);
 }
 
 /* seed_kmer_hash, ref:1322-1373: the first `limit` records whose sequence line is longer than k, of one file,
@@ -536,22 +799,35 @@ int main(int argc, char **argv)
     nc.canonical = cfg.canonical;
     nc.device = getenv("NKML_DEVICE") ? atoi(getenv("NKML_DEVICE")) : 0;
     nc.memory_gb = cfg.memory;
-    nc.max_batch_reads = 1u << 21;
-    nc.max_batch_bases = 400ull << 20;
+    nc.max_batch_reads = 1u << 22;      /* 2 M pairs of 150 bp per batch: where the k=15 path is at its best */
+    nc.max_batch_bases = 640ull << 20;
     if (getenv("NKML_BATCH_READS")) nc.max_batch_reads = (uint32_t)strtoul(getenv("NKML_BATCH_READS"), NULL, 10);
     if (getenv("NKML_BATCH_BASES")) nc.max_batch_bases = strtoull(getenv("NKML_BATCH_BASES"), NULL, 10);
     if (cfg.doprint) nc.flags |= NKML_F_EXACT_COUNTS;
-    int rc = nkml_create(&nc, &ctx);
-    if (rc != NKML_OK) die_nkml("cannot set up the GPU k-mer table", rc);
-    batch_alloc(nc.max_batch_reads, nc.max_batch_bases);
+    {
+        long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+        n_threads = cpus > 16 ? 16 : cpus < 1 ? 1 : (int)cpus; /* host threads of the record loop (not the reference's --cpu) */
+        if (getenv("NKML_THREADS")) n_threads = atoi(getenv("NKML_THREADS"));
+        if (n_threads < 1) n_threads = 1;
+        if (n_threads > MAX_THREADS) n_threads = MAX_THREADS;
+    }
+    timing_on = getenv("NKML_TIMING") != NULL;
+    int rc = 0;
+    TIMED(7, {
+        rc = nkml_create(&nc, &ctx);
+        if (rc != NKML_OK) die_nkml("cannot set up the GPU k-mer table", rc);
+        batch_alloc(nc.max_batch_reads, nc.max_batch_bases);
+    });
 
     /* seeding pass over every input file, before any counting: ref:2242-2250 */
     int seed_n = 1 + (int)(SEED_RECORDS / cfg.n_fwd);
     if (!getenv("NKML_NO_SEED")) {
-        for (int i = 0; i < cfg.n_fwd; i++) {
-            seed_file(cfg.fwd[i], seed_n);
-            if (i < cfg.n_rev) seed_file(cfg.rev[i], seed_n);
-        }
+        TIMED(6, {
+            for (int i = 0; i < cfg.n_fwd; i++) {
+                seed_file(cfg.fwd[i], seed_n);
+                if (i < cfg.n_rev) seed_file(cfg.rev[i], seed_n);
+            }
+        });
     }
     if (cfg.doprint) print_table("_seeds", -1);
 
@@ -626,6 +902,11 @@ int main(int argc, char **argv)
         else printf("Overall processing rate: %'.0f sequences per second\n", (double)tot.processed / runtime);
     } else {
         printf("No data processed\n");
+    }
+    if (timing_on) {
+        fprintf(stderr, "host phases (s):");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.3f", t_name[i], t_phase[i]);
+        fprintf(stderr, " (threads %d)\n", n_threads);
     }
     nkml_destroy(ctx);
     free(name_f);
