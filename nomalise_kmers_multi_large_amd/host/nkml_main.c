@@ -235,25 +235,6 @@ static void unmap_file(struct mapped *m)
     m->size = 0;
 }
 
-/* One record = `lines` lines starting at p.  Fills line starts/lengths, returns the position after the record,
- * or NULL when fewer than `lines` lines remain.  The last line of a file may lack its newline (ref:394-409). */
-static const char *frame_record(const char *p, const char *end, int lines, const char **start, uint32_t *len)
-{
-    for (int i = 0; i < lines; i++) {
-        if (p >= end) return NULL;
-        const char *nl = memchr(p, '\n', (size_t)(end - p));
-        const char *e = nl ? nl : end;
-        if (e - p > MAX_LINE) {
-            fprintf(stderr, "FATAL: input line longer than %d bytes\n", MAX_LINE);
-            exit(EXIT_FAILURE);
-        }
-        start[i] = p;
-        len[i] = (uint32_t)(e - p);
-        p = nl ? nl + 1 : end;
-    }
-    return p;
-}
-
 static const uint8_t base_class[256] = {['A'] = 1, ['C'] = 1, ['G'] = 1, ['T'] = 1, ['N'] = 2}; /* valid_dna after N->A, ref:1144-1158, 1406 */
 
 static bool valid_bases(const char *s, uint32_t n)
@@ -399,7 +380,8 @@ static inline double now_s(void)
 }
 #define TIMED(slot, stmt) do { double t0_ = timing_on ? now_s() : 0; stmt; if (timing_on) t_phase[slot] += now_s() - t0_; } while (0)
 static nkml_ctx *ctx;
-static FILE *out_fwd, *out_rev;
+static int out_fd[2] = {-1, -1};  /* forward / reverse output files */
+static off_t out_off[2];          /* bytes written so far */
 static struct totals tot;
 
 static void die_nkml(const char *what, int rc)
@@ -420,13 +402,6 @@ static void batch_alloc(uint32_t cap_reads, uint64_t cap_bases)
     B.total = malloc((size_t)cap_reads * sizeof(int32_t));
     if (!B.rec || !B.high || !B.total) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
     B.offsets[0] = 0;
-}
-
-static inline void stage_read(const char *s, uint32_t n)
-{
-    memcpy(B.seq + B.n_bases, s, n);
-    B.n_bases += n;
-    B.offsets[++B.n_reads] = B.n_bases;
 }
 
 static inline float ratio_f32(int32_t high, int32_t total)
@@ -585,6 +560,25 @@ static void format_records(int tid, int nt, void *arg)
     P.t_printed[tid] = printed;
 }
 
+/* Phase 4: every thread writes its buffer at its place in the output files (input order = thread order) */
+static void write_records(int tid, int nt, void *arg)
+{
+    (void)arg;
+    (void)nt;
+    for (int f = 0; f < 2; f++) {
+        size_t n = P.olen[f][tid];
+        if (!n || out_fd[f] < 0) continue;
+        off_t at = out_off[f];
+        for (int t = 0; t < tid; t++) at += (off_t)P.olen[f][t];
+        const char *p = P.obuf[f][tid];
+        while (n) {
+            ssize_t w = pwrite(out_fd[f], p, n, at);
+            if (w < 0) { perror("Error writing output"); exit(EXIT_FAILURE); }
+            p += w; n -= (size_t)w; at += w;
+        }
+    }
+}
+
 /* Count the staged batch on the GPU, then decide and write in input order. */
 static void flush_batch(void)
 {
@@ -598,9 +592,10 @@ static void flush_batch(void)
     });
     TIMED(4, parallel_run(format_records, NULL));
     TIMED(5, {
+        parallel_run(write_records, NULL);
         for (int t = 0; t < n_threads; t++) {
-            if (P.olen[0][t]) fwrite(P.obuf[0][t], 1, P.olen[0][t], out_fwd);
-            if (P.olen[1][t]) fwrite(P.obuf[1][t], 1, P.olen[1][t], out_rev);
+            out_off[0] += (off_t)P.olen[0][t];
+            out_off[1] += (off_t)P.olen[1][t];
         }
     });
     if (cfg.debug > 1) {
@@ -711,38 +706,83 @@ static void seed_file(const char *name, int limit)
     if (cfg.verbose) printf("Seeding hash table with up to %'d records from file %s\n", limit, name);
     struct mapped m = map_file(name);
     if (!m.data) return;
-    const int lines = cfg.fastq_in ? 4 : 2;
-    const char *p = m.data, *end = m.data + m.size;
+    P.lines = cfg.fastq_in ? 4 : 2;
+    P.paired = false;
+    P.K = (uint32_t)cfg.ksize + 1; /* strictly longer than k, ref:1352 */
+    size_t size = m.size;
     /* the reference only sees complete, newline-terminated lines: stop at the last newline */
-    while (end > p && end[-1] != '\n') end--;
-    const char *s[4];
-    uint32_t l[4];
-    int done = 0;
-    const uint32_t K = (uint32_t)cfg.ksize;
-    while (done < limit) {
-        const char *n = frame_record(p, end, lines, s, l);
-        if (!n) break;
-        if (l[1] > K) {
-            if (!valid_bases(s[1], l[1])) { fatal_sequence("FWD", s[1], l[1]); exit(EXIT_FAILURE); }
-            if (B.n_reads + 1 > B.cap_reads || B.n_bases + l[1] > B.cap_bases) {
-                int rc = nkml_seed(ctx, B.seq, B.offsets, B.n_reads);
-                if (rc != NKML_OK) die_nkml("seed", rc);
-                B.n_reads = 0; B.n_bases = 0;
-            }
-            stage_read(s[1], l[1]);
-            done++;
+    while (size > 0 && m.data[size - 1] != '\n') size--;
+    size_t pos = 0, done = 0, bytes_per_rec = 512;
+    while (done < (size_t)limit) {
+        size_t want = (size_t)B.cap_reads * bytes_per_rec;
+        if (want > (size_t)3 << 30) want = (size_t)3 << 30;
+        const size_t w = size - pos < want ? size - pos : want;
+        build_index(&P.F, m.data + pos, w, false);
+        size_t n_rec = P.F.n_lines / (size_t)P.lines;
+        if (n_rec > B.cap_reads) n_rec = B.cap_reads;
+        if (n_rec == 0) break;
+        if (n_rec > B.cap_use) {
+            free(B.use);
+            B.cap_use = n_rec + n_rec / 8;
+            B.use = malloc(B.cap_use);
+            if (!B.use) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
         }
-        p = n;
-    }
-    if (B.n_reads) {
-        int rc = nkml_seed(ctx, B.seq, B.offsets, B.n_reads);
-        if (rc != NKML_OK) die_nkml("seed", rc);
-        B.n_reads = 0; B.n_bases = 0;
+        size_t units, bases;
+        for (;;) {
+            P.n_rec = n_rec;
+            P.long_line = 0;
+            parallel_run(size_records, NULL);
+            if (P.long_line) {
+                fprintf(stderr, "FATAL: input line longer than %d bytes\n", MAX_LINE);
+                exit(EXIT_FAILURE);
+            }
+            size_t bad = SIZE_MAX;
+            for (int t = 0; t < n_threads; t++)
+                if (P.t_bad[t] < bad) bad = P.t_bad[t];
+            units = bases = 0;
+            size_t cut = SIZE_MAX; /* record at which the limit is reached, if it is reached in this window */
+            for (int t = 0; t < n_threads && cut == SIZE_MAX; t++) {
+                size_t a, e;
+                rec_range(n_rec, t, n_threads, &a, &e);
+                if (a > bad) break;
+                if (units + P.t_units[t] > (size_t)limit - done) {
+                    size_t have = units;
+                    for (size_t i = a; i < e; i++)
+                        if (B.use[i] && ++have == (size_t)limit - done) { cut = i; break; }
+                }
+                units += P.t_units[t];
+                bases += P.t_bases[t];
+            }
+            if (cut != SIZE_MAX && cut + 1 < n_rec) { n_rec = cut + 1; continue; } /* only the records up to the limit */
+            if (bad != SIZE_MAX) { /* a record the reference would have stopped at before reaching the limit */
+                uint32_t len;
+                const char *sq = seq_line(&P.F, P.lines, bad, &len);
+                fatal_sequence("FWD", sq, len);
+                exit(EXIT_FAILURE);
+            }
+            if (bases <= B.cap_bases) break;
+            n_rec = (size_t)((double)n_rec * (double)B.cap_bases / (double)bases * 0.98);
+            if (n_rec == 0) n_rec = 1;
+        }
+        B.n_units = B.n_reads = (uint32_t)units;
+        B.n_bases = bases;
+        if (units) {
+            parallel_run(stage_records, NULL);
+            int rc = nkml_seed(ctx, B.seq, B.offsets, B.n_reads);
+            if (rc != NKML_OK) die_nkml("seed", rc);
+        }
+        done += units;
+        B.n_reads = B.n_units = 0;
+        B.n_bases = 0;
+        const size_t last = n_rec * (size_t)P.lines - 1;
+        const size_t used = line_end(&P.F, last) + 1;
+        pos += used;
+        bytes_per_rec = used / n_rec + 64;
     }
     if (cfg.verbose) {
         nkml_stats st;
         nkml_get_stats(ctx, &st);
-        printf("%'d records with %'zu kmers seeded\n", done, (size_t)st.unique_kmers);
+        printf("%'zu records with %'zu kmers seeded\n", done, (size_t)st.unique_kmers);
     }
     unmap_file(&m);
 }
@@ -831,17 +871,14 @@ int main(int argc, char **argv)
     }
     if (cfg.doprint) print_table("_seeds", -1);
 
-    static char buf_f[1 << 20], buf_r[1 << 20];
     char *name_f = output_name("output_forward", cfg.ksize, cfg.depth, 0, "fastq"); /* ref:2286: always .fastq */
-    out_fwd = fopen(name_f, "w");
-    if (!out_fwd) { fprintf(stderr, "Error opening file to write: %s\n", name_f); return EXIT_FAILURE; }
-    setvbuf(out_fwd, buf_f, _IOFBF, sizeof buf_f);
+    out_fd[0] = open(name_f, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (out_fd[0] < 0) { fprintf(stderr, "Error opening file to write: %s\n", name_f); return EXIT_FAILURE; }
     char *name_r = NULL;
     if (cfg.n_rev != 0) { /* ref:2294 */
         name_r = output_name("output_reverse", cfg.ksize, cfg.depth, 0, "fastq");
-        out_rev = fopen(name_r, "w");
-        if (!out_rev) { fprintf(stderr, "Error opening file to write: %s\n", name_r); return EXIT_FAILURE; }
-        setvbuf(out_rev, buf_r, _IOFBF, sizeof buf_r);
+        out_fd[1] = open(name_r, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (out_fd[1] < 0) { fprintf(stderr, "Error opening file to write: %s\n", name_r); return EXIT_FAILURE; }
     }
 
     struct timespec t0, t1;
@@ -884,8 +921,8 @@ int main(int argc, char **argv)
         unmap_file(&mf);
         if (paired) unmap_file(&mr);
     }
-    fclose(out_fwd);
-    if (out_rev) fclose(out_rev);
+    close(out_fd[0]);
+    if (out_fd[1] >= 0) close(out_fd[1]);
     if (cfg.doprint) print_table("", 0);
 
     /* ref:2415-2419, 2438-2453 */
