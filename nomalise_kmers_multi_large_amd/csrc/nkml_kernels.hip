@@ -857,10 +857,25 @@ __global__ void __launch_bounds__(256) k_reduce_reads(const uint8_t *__restrict_
     int lane = threadIdx.x & 63;
     uint64_t a = offsets[r], b = offsets[r + 1];
     uint32_t h = 0, t = 0;
-    for (uint64_t p = a + lane; p < b; p += 64) {
-        uint32_t f = flags[p];
-        h += f == FLAG_HIGH;
-        t += f != FLAG_NONE;
+    if ((reinterpret_cast<uintptr_t>(flags) & 3u) == 0) {
+        // four flags per lane and load (aligned words; bytes outside [a, b) are masked off): one round for reads of
+        // up to 253 bases.  FLAG_HIGH = 1, FLAG_LOW = 2, so per byte bit 0 = high and (bit 0 | bit 1) = counted.
+        static_assert(FLAG_NONE == 0 && FLAG_HIGH == 1 && FLAG_LOW == 2, "flag encoding");
+        for (uint64_t p = (a & ~3ull) + 4ull * lane; p < b; p += 256) {
+            uint32_t w = *reinterpret_cast<const uint32_t *>(flags + p);
+            uint32_t m = 0xffffffffu;
+            if (p < a) m &= 0xffffffffu << (8 * (a - p));
+            if (p + 4 > b) m &= 0xffffffffu >> (8 * (p + 4 - b));
+            w &= m;
+            h += __popc(w & 0x01010101u);
+            t += __popc((w | (w >> 1)) & 0x01010101u);
+        }
+    } else {
+        for (uint64_t p = a + lane; p < b; p += 64) {
+            uint32_t f = flags[p];
+            h += f == FLAG_HIGH;
+            t += f != FLAG_NONE;
+        }
     }
     h = wave_sum(h);
     t = wave_sum(t);

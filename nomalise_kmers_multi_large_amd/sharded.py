@@ -94,7 +94,7 @@ class HipShardEngine:
 class ShardedNormaliser:
     """One step = every rank's batch of reads, processed as one global batch (rank-major stream order)."""
 
-    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False):
+    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=256 << 20):
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group)
@@ -103,8 +103,32 @@ class ShardedNormaliser:
         # rehearsal aid only: lets several ranks share one GPU under the gloo backend (RCCL refuses two ranks on
         # one device) by bouncing the exchanged buffers through host memory
         self.stage_through_host = stage_through_host
+        self.max_message_bytes = max_message_bytes
 
-    def _all_to_all(self, out, inp, out_splits, in_splits):
+    def _all_to_all(self, out, inp, out_splits, in_splits, peak):
+        """out/inp: per-peer segments back to back.  `peak` is the largest segment anywhere in the job (the same
+        number on every rank); segments are exchanged in rounds of at most max_message_bytes each, because one
+        RCCL message of more than 1 GiB was seen to arrive cut in half (ROCm 7.0, all_to_all_single, int32)."""
+        limit = max(1, self.max_message_bytes // inp.element_size())
+        rounds = max(1, -(-peak // limit))
+        if rounds == 1:
+            self._all_to_all_once(out, inp, out_splits, in_splits)
+            return
+        in_at = np.concatenate([[0], np.cumsum(in_splits)])
+        out_at = np.concatenate([[0], np.cumsum(out_splits)])
+        for r in range(rounds):
+            lo = r * limit
+            isz = [int(min(max(n - lo, 0), limit)) for n in in_splits]
+            osz = [int(min(max(n - lo, 0), limit)) for n in out_splits]
+            piece_in = torch.cat([inp[int(in_at[p]) + lo: int(in_at[p]) + lo + isz[p]] for p in range(self.world)])
+            piece_out = torch.empty(sum(osz), dtype=out.dtype, device=out.device)
+            self._all_to_all_once(piece_out, piece_in, osz, isz)
+            at = 0
+            for p in range(self.world):
+                out[int(out_at[p]) + lo: int(out_at[p]) + lo + osz[p]].copy_(piece_out[at: at + osz[p]])
+                at += osz[p]
+
+    def _all_to_all_once(self, out, inp, out_splits, in_splits):
         if not self.stage_through_host or not inp.is_cuda:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
             return
@@ -126,10 +150,14 @@ class ShardedNormaliser:
         return [b.to(packed.device) for b in bufs] if host else bufs
 
     def _exchange_counts(self, send_counts, like):
-        sc = torch.tensor(send_counts, dtype=torch.int64, device="cpu" if self.stage_through_host else like.device)
+        """What every peer sends here, and the largest segment of the whole exchange (for the round count)."""
+        cdev = "cpu" if self.stage_through_host or not like.is_cuda else like.device
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=cdev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
-        return [int(x) for x in rc.tolist()]
+        peak = sc.max().reshape(1).clone()
+        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=self.group)
+        return [int(x) for x in rc.tolist()], int(peak.item())
 
     def process_step(self, seq, offsets, n_reads, n_bases):
         """seq/offsets: this rank's reads (device tensors for the HIP engine).  Returns (high, total) of this
@@ -137,12 +165,12 @@ class ShardedNormaliser:
         eng, W = self.eng, self.world
         keys = eng.kmerise(seq, offsets, n_reads, n_bases)
         send_keys, send_src, send_counts = eng.route(keys, W)
-        recv_counts = self._exchange_counts(send_counts, send_keys)
+        recv_counts, peak = self._exchange_counts(send_counts, send_keys)
         recv_keys = eng.recv_buffer(sum(recv_counts))
-        self._all_to_all(recv_keys, send_keys, recv_counts, send_counts)
+        self._all_to_all(recv_keys, send_keys, recv_counts, send_counts, peak)
         recv_flags = eng.count(recv_keys)
         back = eng.back_buffer(sum(send_counts))
-        self._all_to_all(back, recv_flags, send_counts, recv_counts)
+        self._all_to_all(back, recv_flags, send_counts, recv_counts, peak)
         flags = eng.unroute(back, send_src, keys.numel())
         high, total = eng.reduce(flags, offsets, n_reads)
         gathered = None

@@ -1,5 +1,7 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and with the vectors captured from the
 compiled reference.  Integer work: every comparison is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -336,3 +338,42 @@ def test_partitioned_equals_atomic_path_on_synthetic_pairs(nk):
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2]
+
+
+def test_sharded_normaliser_over_rccl_world_of_one(nk):
+    """ShardedNormaliser end to end over the real RCCL backend (world size 1 on this box): k=15, so the owner counts
+    with the partitioned path from a key array; the exchange is forced into several rounds per step.  Per-read
+    counters must equal those of the single-table path on the same stream."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.sharded import HipShardEngine, ShardedNormaliser
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bp = 20000
+        eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150)
+        sn = ShardedNormaliser(eng, max_message_bytes=1 << 20)
+        with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
+            h = torch.zeros(2 * bp, dtype=torch.int32, device="cuda")
+            t = torch.zeros_like(h)
+            for c1, c2 in synth.pair_blocks(3 * bp, seed=5, transcripts=40, block=bp):
+                seq, off = synth.interleave(c1, c2)
+                d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+                nr, nb = len(off) - 1, len(seq)
+                high, total, gathered = sn.process_step(d_seq, d_off, nr, nb)
+                g.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, nb, h.data_ptr(), t.data_ptr())
+                sn.synchronize()
+                g.synchronize()
+                np.testing.assert_array_equal(high.cpu().numpy(), h[:nr].cpu().numpy())
+                np.testing.assert_array_equal(total.cpu().numpy(), t[:nr].cpu().numpy())
+                np.testing.assert_array_equal(gathered[0][0].cpu().numpy(), h[:nr].cpu().numpy())
+            assert int(h.sum()) > 0 and eng.stats()["unique_kmers"] == g.unique_kmers
+    finally:
+        dist.destroy_process_group()

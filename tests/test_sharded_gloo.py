@@ -79,13 +79,13 @@ def concat(reads):
     return np.frombuffer(b"".join(reads), dtype=np.uint8).copy(), off
 
 
-def worker(rank, world, port, k, depth, canonical, steps, q):
+def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=256 << 20):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
-        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical))
+        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical), max_message_bytes=max_message_bytes)
         out = []
         for step in range(steps):
             reads = make_reads(100 * step + rank, 40 + 7 * rank, k, 90)   # ragged: ranks bring different amounts
@@ -109,13 +109,15 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,k,depth,canonical", [(2, 9, 3, False), (2, 21, 2, True), (3, 11, 4, True)])
-def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical):
+# the last case exchanges in rounds of at most 1000 bytes per message (several rounds per step)
+@pytest.mark.parametrize("world,k,depth,canonical,msg", [(2, 9, 3, False, 256 << 20), (2, 21, 2, True, 256 << 20), (3, 11, 4, True, 256 << 20),
+                                                         (2, 11, 3, True, 1000)])
+def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg):
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg)) for r in range(world)]
     for p in procs:
         p.start()
     got, uniq = q.get(timeout=120)
