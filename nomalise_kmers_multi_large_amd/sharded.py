@@ -94,7 +94,7 @@ class HipShardEngine:
 class ShardedNormaliser:
     """One step = every rank's batch of reads, processed as one global batch (rank-major stream order)."""
 
-    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=256 << 20):
+    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=512 << 20):
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group)
@@ -108,7 +108,7 @@ class ShardedNormaliser:
     def _all_to_all(self, out, inp, out_splits, in_splits, peak):
         """out/inp: per-peer segments back to back.  `peak` is the largest segment anywhere in the job (the same
         number on every rank); segments are exchanged in rounds of at most max_message_bytes each, because one
-        RCCL message of more than 1 GiB was seen to arrive cut in half (ROCm 7.0, all_to_all_single, int32)."""
+        message of more than 1024 MiB arrives cut in half through all_to_all_single on this stack (RCCL 2.26.6 of torch 2.10+rocm7.0; tools/rccl_msg_check.py: 1024 MiB whole, 1025 MiB half lost)."""
         limit = max(1, self.max_message_bytes // inp.element_size())
         rounds = max(1, -(-peak // limit))
         if rounds == 1:
