@@ -1154,18 +1154,29 @@ int alloc_table(nkml_ctx *c)
     return NKML_OK;
 }
 
+// hipMemsetAsync in pieces of 1 GiB (tables here reach 8 GiB and more)
+hipError_t zero_device(void *p, uint64_t bytes, hipStream_t stream)
+{
+    const uint64_t piece = 1ull << 30;
+    for (uint64_t at = 0; at < bytes; at += piece) {
+        hipError_t e = hipMemsetAsync(static_cast<char *>(p) + at, 0, bytes - at < piece ? bytes - at : piece, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int clear_table(nkml_ctx *c)
 {
     if (c->partitioned) {
         const uint64_t bytes = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
-        HIPCHK(c, hipMemsetAsync(c->pt_table, 0, bytes, c->stream));
+        HIPCHK(c, zero_device(c->pt_table, bytes, c->stream));
     } else if (c->direct) {
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
-        HIPCHK(c, hipMemsetAsync(c->counts, 0, c->capacity * sizeof(uint32_t), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->sat, 0, bm, c->stream));
-        if (c->extra) HIPCHK(c, hipMemsetAsync(c->extra, 0, c->capacity * sizeof(uint32_t), c->stream));
+        HIPCHK(c, zero_device(c->counts, c->capacity * sizeof(uint32_t), c->stream));
+        HIPCHK(c, zero_device(c->sat, bm, c->stream));
+        if (c->extra) HIPCHK(c, zero_device(c->extra, c->capacity * sizeof(uint32_t), c->stream));
     } else {
-        HIPCHK(c, hipMemsetAsync(c->slots, 0, c->capacity * sizeof(Slot), c->stream));
+        HIPCHK(c, zero_device(c->slots, c->capacity * sizeof(Slot), c->stream));
     }
     if (c->filter) HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
@@ -1193,7 +1204,7 @@ int ensure_capacity(nkml_ctx *c, uint64_t incoming)
         uint64_t ncap = c->capacity * 2;
         Slot *ns = nullptr;
         HIPCHK(c, hipMalloc(&ns, ncap * sizeof(Slot)));
-        HIPCHK(c, hipMemsetAsync(ns, 0, ncap * sizeof(Slot), c->stream));
+        HIPCHK(c, zero_device(ns, ncap * sizeof(Slot), c->stream));
         hipLaunchKernelGGL(k_rehash, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, ns, ncap - 1, c->d_ctr);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1347,9 +1358,10 @@ int run_fused(nkml_ctx *c, uint64_t n_bases, bool seeding)
     const int exact = (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0;
     const int k = c->cfg.ksize;
     const bool canon = c->cfg.canonical != 0;
-    const uint64_t n_words = (n_bases + 15) / 16, mask = c->capacity - 1;
+    const uint64_t n_words = (n_bases + 15) / 16;
     int rc;
     if ((rc = ensure_capacity(c, n_words * 16)) != NKML_OK) return rc;
+    const uint64_t mask = c->capacity - 1; // after the table has grown, not before
     if (seeding) {
 #define SEED_LAUNCH(CANON, DIRECT) hipLaunchKernelGGL((k_seed_words<CANON, DIRECT>), GRID_PERSIST, 256, 0, c->stream, c->d_packed, c->d_startbits, \
                                                       n_bases, n_words, k, c->counts, c->slots, mask, c->d_ctr)

@@ -377,3 +377,35 @@ def test_sharded_normaliser_over_rccl_world_of_one(nk):
             assert int(h.sum()) > 0 and eng.stats()["unique_kmers"] == g.unique_kmers
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,canonical,batch_pairs,want_kept,want_unique", [
+    (15, False, 2000000, 1011077, 28393181),   # one batch: 544 M k-mers through the partitioned path at its working size
+    (15, False, 700000, 1011077, 28393181),    # ragged batches: the answer does not depend on the cuts
+    (25, True, 1000000, 883957, 33851135),     # hashed table, canonical k-mers, growth from the default capacity
+])
+def test_known_answer_two_million_synthetic_pairs(nk, k, canonical, batch_pairs, want_kept, want_unique):
+    """The 2 M-pair synthetic dataset (seed 1, 2000 transcripts) whose answer the reference gives with a
+    collision-free table (-m 16 at k=15) and the CPU oracle reproduces: kept pairs and distinct k-mers."""
+    import torch
+    from nomalise_kmers_multi_large_amd import synth
+    n = 2000000
+    kept = 0
+    with nk.KmerNormaliser(k, 100, 0.9, canonical, max_batch_reads=2 * batch_pairs, max_batch_bases=2 * batch_pairs * 150) as g:
+        h = torch.zeros(2 * batch_pairs, dtype=torch.int32, device="cuda")
+        t = torch.zeros_like(h)
+        keep = torch.zeros(batch_pairs, dtype=torch.uint8, device="cuda")
+        # the dataset is defined with the generator's default block size (its random stream depends on it)
+        blocks = list(synth.pair_blocks(n, seed=1, transcripts=2000))
+        a1, a2 = np.concatenate([b[0] for b in blocks]), np.concatenate([b[1] for b in blocks])
+        del blocks
+        for at in range(0, n, batch_pairs):
+            seq, off = synth.interleave(a1[at:at + batch_pairs], a2[at:at + batch_pairs])
+            d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+            nr = len(off) - 1
+            g.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, len(seq), h.data_ptr(), t.data_ptr())
+            g.decide_device(h.data_ptr(), t.data_ptr(), nr // 2, True, keep.data_ptr())
+            g.synchronize()
+            kept += int(keep[: nr // 2].sum())
+        assert kept == want_kept
+        assert g.unique_kmers == want_unique
