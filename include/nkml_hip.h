@@ -162,6 +162,10 @@ int nkml_reduce_reads_device(nkml_ctx *ctx, const void *d_keys, const uint8_t *d
 int nkml_owner_of(uint64_t key, uint32_t n_shards);
 int nkml_route_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
                            uint32_t *d_send_src, uint64_t *send_counts);
+/*   route_reads   : the same partition taken straight from a batch of reads (k-mers recomputed from the packed
+ *                   sequence, no key array in between); positions in d_send_src are base positions of the batch. */
+int nkml_route_reads_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
+                            uint32_t n_shards, void *d_send_keys, uint32_t *d_send_src, uint64_t *send_counts);
 int nkml_unroute_flags_device(nkml_ctx *ctx, const uint8_t *d_recv_flags, const uint32_t *d_send_src, uint64_t n_sent,
                               uint8_t *d_flags, uint64_t n_keys);
 

@@ -848,20 +848,20 @@ __global__ void __launch_bounds__(256) k_rehash(const Slot *__restrict__ old_slo
 
 // ------------------------------------------------------------------------------------------------------
 // K5: per read, high = flags equal to HIGH, total = flags that are not NONE, i.e. windows with a non-zero code
-// (sequence_to_hash's two counters, normalise_kmers_multi_large.c:1486, 1496).  One wavefront per read.
+// (sequence_to_hash's two counters, normalise_kmers_multi_large.c:1486, 1496).  Sixteen lanes per read.
 __global__ void __launch_bounds__(256) k_reduce_reads(const uint8_t *__restrict__ flags, const uint64_t *__restrict__ offsets,
                                                       uint32_t n_reads, int32_t *__restrict__ high, int32_t *__restrict__ total)
 {
-    uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_reads) return;
-    int lane = threadIdx.x & 63;
-    uint64_t a = offsets[r], b = offsets[r + 1];
+    const uint32_t r = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = r < n_reads; // no early exit: the lanes of a wavefront shuffle together below
+    const int lane = threadIdx.x & 15;
+    const uint64_t a = live ? offsets[r] : 0, b = live ? offsets[r + 1] : 0;
     uint32_t h = 0, t = 0;
     if ((reinterpret_cast<uintptr_t>(flags) & 3u) == 0) {
-        // four flags per lane and load (aligned words; bytes outside [a, b) are masked off): one round for reads of
-        // up to 253 bases.  FLAG_HIGH = 1, FLAG_LOW = 2, so per byte bit 0 = high and (bit 0 | bit 1) = counted.
+        // four flags per lane and load (aligned words; bytes outside [a, b) are masked off): three rounds for a read
+        // of 150 bases.  FLAG_HIGH = 1, FLAG_LOW = 2, so per byte bit 0 = high and (bit 0 | bit 1) = counted.
         static_assert(FLAG_NONE == 0 && FLAG_HIGH == 1 && FLAG_LOW == 2, "flag encoding");
-        for (uint64_t p = (a & ~3ull) + 4ull * lane; p < b; p += 256) {
+        for (uint64_t p = (a & ~3ull) + 4ull * lane; p < b; p += 64) {
             uint32_t w = *reinterpret_cast<const uint32_t *>(flags + p);
             uint32_t m = 0xffffffffu;
             if (p < a) m &= 0xffffffffu << (8 * (a - p));
@@ -871,15 +871,18 @@ __global__ void __launch_bounds__(256) k_reduce_reads(const uint8_t *__restrict_
             t += __popc((w | (w >> 1)) & 0x01010101u);
         }
     } else {
-        for (uint64_t p = a + lane; p < b; p += 64) {
+        for (uint64_t p = a + lane; p < b; p += 16) {
             uint32_t f = flags[p];
             h += f == FLAG_HIGH;
             t += f != FLAG_NONE;
         }
     }
-    h = wave_sum(h);
-    t = wave_sum(t);
-    if (lane == 0) { high[r] = (int32_t)h; total[r] = (int32_t)t; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        h += __shfl_xor(h, o);
+        t += __shfl_xor(t, o);
+    }
+    if (live && lane == 0) { high[r] = (int32_t)h; total[r] = (int32_t)t; }
 }
 
 // Keep/skip, float32, strict '<' (normalise_kmers_multi_large.c:1641-1646, 1988-1992).  __fdiv_rn is the IEEE
@@ -916,19 +919,58 @@ __host__ __device__ __forceinline__ uint32_t owner_of(unsigned long long key, ui
     return (uint32_t)(((key * 0x9E3779B97F4A7C15ull) >> 32) % n_shards);
 }
 
-template <typename KEY>
-__global__ void __launch_bounds__(256) k_route_count(const KEY *__restrict__ keys, uint64_t n, uint32_t n_shards, uint64_t n_waves,
+// Where a routing tile's keys come from: a key array (one key per base position), or the packed words of the
+// batch (keys recomputed, never stored: 16 per lane, handed over in position order through LDS).
+struct RouteSource {
+    const void *keys;           // SRC == 0
+    const uint32_t *packed;     // SRC != 0
+    const uint32_t *startbits;
+    uint64_t n_bases;
+    int k;
+};
+constexpr int ROUTE_STAGE = ROUTE_TILE + ROUTE_TILE / 16; // 17 slots per packed word: conflict-free both ways
+
+template <typename KEY, int SRC>
+__device__ __forceinline__ void route_stage_tile(const RouteSource &src, uint64_t wv, uint64_t n, bool live_wave, KEY *stage)
+{
+    if (SRC != 0) {
+        const int lane = threadIdx.x & 63;
+        if (live_wave) { // wavefront-uniform: every lane takes part in the shuffles of word_keys
+            const uint64_t w = wv * (ROUTE_TILE / 16) + lane, n_words = n / 16;
+            KEY out[16];
+            word_keys<KEY, SRC == 2>(src.packed, src.startbits, w, w < n_words, src.n_bases, src.k, out);
+#pragma unroll
+            for (int j = 0; j < 16; j++) stage[lane * 17 + j] = out[j];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename KEY, int SRC>
+__device__ __forceinline__ unsigned long long route_key(const RouteSource &src, const KEY *stage, uint64_t base, int it, int lane, uint64_t n)
+{
+    if (SRC != 0) {
+        const int p = it * 64 + lane;
+        return (unsigned long long)stage[p + (p >> 4)];
+    }
+    const uint64_t i = base + it * 64 + lane;
+    return i < n ? (unsigned long long)static_cast<const KEY *>(src.keys)[i] : 0ull;
+}
+
+template <typename KEY, int SRC>
+__global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves,
                                                      uint32_t *__restrict__ hist)
 {
-    uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= n_waves) return;
+    __shared__ KEY stage[SRC != 0 ? 4 : 1][SRC != 0 ? ROUTE_STAGE : 1];
+    const uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live_wave = wv < n_waves;
+    route_stage_tile<KEY, SRC>(src, wv, n, live_wave, stage[SRC != 0 ? threadIdx.x >> 6 : 0]);
+    if (!live_wave) return;
     int lane = threadIdx.x & 63;
     uint64_t base = wv * ROUTE_TILE;
-    for (uint32_t sh = lane; sh < n_shards; sh += 64) hist[(uint64_t)sh * n_waves + wv] = 0; // n_shards <= 64: one lane each
-    uint32_t mine = 0; // lane sh accumulates the count of shard sh
+    uint32_t mine = 0; // lane sh accumulates the count of shard sh (n_shards <= 64: one lane each)
     for (int it = 0; it < ROUTE_TILE / 64; it++) {
-        uint64_t i = base + it * 64 + lane;
-        unsigned long long key = i < n ? (unsigned long long)keys[i] : 0ull;
+        unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
         uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
         for (uint32_t sh = 0; sh < n_shards; sh++) {
             unsigned long long m = __ballot(own == sh);
@@ -938,19 +980,22 @@ __global__ void __launch_bounds__(256) k_route_count(const KEY *__restrict__ key
     if ((uint32_t)lane < n_shards) hist[(uint64_t)lane * n_waves + wv] = mine;
 }
 
-template <typename KEY>
-__global__ void __launch_bounds__(256) k_route_scatter(const KEY *__restrict__ keys, uint64_t n, uint32_t n_shards, uint64_t n_waves,
+template <typename KEY, int SRC>
+__global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves,
                                                        const uint32_t *__restrict__ offsets, KEY *__restrict__ send_keys,
                                                        uint32_t *__restrict__ send_src)
 {
-    uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= n_waves) return;
+    __shared__ KEY stage[SRC != 0 ? 4 : 1][SRC != 0 ? ROUTE_STAGE : 1];
+    const uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool live_wave = wv < n_waves;
+    route_stage_tile<KEY, SRC>(src, wv, n, live_wave, stage[SRC != 0 ? threadIdx.x >> 6 : 0]);
+    if (!live_wave) return;
     int lane = threadIdx.x & 63;
     uint64_t base = wv * ROUTE_TILE;
     uint32_t next = (uint32_t)lane < n_shards ? offsets[(uint64_t)lane * n_waves + wv] : 0u; // lane sh: next free slot of shard sh
     for (int it = 0; it < ROUTE_TILE / 64; it++) {
         uint64_t i = base + it * 64 + lane;
-        unsigned long long key = i < n ? (unsigned long long)keys[i] : 0ull;
+        unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
         uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
         uint32_t dst = 0;
         for (uint32_t sh = 0; sh < n_shards; sh++) {
@@ -1411,7 +1456,7 @@ int run_fused(nkml_ctx *c, uint64_t n_bases, bool seeding)
 int run_reduce(nkml_ctx *c, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high, int32_t *d_total)
 {
     if (n_reads == 0) return NKML_OK;
-    hipLaunchKernelGGL(k_reduce_reads, blocks_for(n_reads, 4), 256, 0, c->stream, d_flags, d_offsets, n_reads, d_high, d_total);
+    hipLaunchKernelGGL(k_reduce_reads, blocks_for(n_reads, 16), 256, 0, c->stream, d_flags, d_offsets, n_reads, d_high, d_total);
     HIPCHK(c, hipGetLastError());
     return NKML_OK;
 }
@@ -1885,12 +1930,12 @@ int nkml_decide_device(nkml_ctx *c, const int32_t *d_high, const int32_t *d_tota
 
 int nkml_owner_of(uint64_t key, uint32_t n_shards) { return n_shards ? (int)owner_of(key, n_shards) : NKML_E_ARG; }
 
-int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
-                           uint32_t *d_send_src, uint64_t *send_counts)
+// Stable partition of one batch's keys by owning shard.  d_keys != nullptr: from a key array; else from the packed
+// words the context prepared (n_bases of them).
+static int route_common(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t n_bases, uint32_t n_shards, void *d_send_keys,
+                        uint32_t *d_send_src, uint64_t *send_counts)
 {
-    if (!c || !d_keys || !d_send_keys || !d_send_src || !send_counts || n_shards == 0 || n_shards > 64) return NKML_E_ARG;
     if (n_keys >= (1ull << 32)) return fail(c, NKML_E_ARG, "too many keys for 32-bit source positions");
-    HIPCHK(c, hipSetDevice(c->cfg.device));
     for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = 0;
     if (n_keys == 0) return NKML_OK;
     const uint64_t n_waves = (n_keys + ROUTE_TILE - 1) / ROUTE_TILE;
@@ -1910,19 +1955,24 @@ int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
     }
     const uint32_t grid = blocks_for(n_waves, 4);
     HIPCHK(c, hipMemsetAsync(c->d_route_hist + entries, 0, sizeof(uint32_t), c->stream)); // one extra entry: the scan's last output = total
-    if (c->key_bytes == 4)
-        hipLaunchKernelGGL((k_route_count<uint32_t>), grid, 256, 0, c->stream, (const uint32_t *)d_keys, n_keys, n_shards, n_waves, c->d_route_hist);
-    else
-        hipLaunchKernelGGL((k_route_count<unsigned long long>), grid, 256, 0, c->stream, (const unsigned long long *)d_keys, n_keys, n_shards, n_waves, c->d_route_hist);
+    RouteSource src = {d_keys, c->d_packed, c->d_startbits, n_bases, c->cfg.ksize};
+    const int mode = d_keys ? 0 : c->cfg.canonical ? 2 : 1;
+#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, c->d_route_hist)
+#define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, c->d_route_off, \
+                                                   (KEY *)d_send_keys, d_send_src)
+#define ROUTE_DISPATCH(WHAT)                                                                                      \
+    do {                                                                                                          \
+        if (c->key_bytes == 4) { if (mode == 0) WHAT(uint32_t, 0); else if (mode == 1) WHAT(uint32_t, 1); else WHAT(uint32_t, 2); } \
+        else { if (mode == 0) WHAT(unsigned long long, 0); else if (mode == 1) WHAT(unsigned long long, 1); else WHAT(unsigned long long, 2); } \
+    } while (0)
+    ROUTE_DISPATCH(ROUTE_COUNT);
     HIPCHK(c, hipGetLastError());
     size_t tmp = c->route_tmp_bytes;
     HIPCHK(c, rocprim::exclusive_scan(c->d_route_tmp, tmp, c->d_route_hist, c->d_route_off, 0u, (size_t)(entries + 1), rocprim::plus<uint32_t>(), c->stream));
-    if (c->key_bytes == 4)
-        hipLaunchKernelGGL((k_route_scatter<uint32_t>), grid, 256, 0, c->stream, (const uint32_t *)d_keys, n_keys, n_shards, n_waves, c->d_route_off,
-                           (uint32_t *)d_send_keys, d_send_src);
-    else
-        hipLaunchKernelGGL((k_route_scatter<unsigned long long>), grid, 256, 0, c->stream, (const unsigned long long *)d_keys, n_keys, n_shards, n_waves,
-                           c->d_route_off, (unsigned long long *)d_send_keys, d_send_src);
+    ROUTE_DISPATCH(ROUTE_SCATTER);
+#undef ROUTE_DISPATCH
+#undef ROUTE_SCATTER
+#undef ROUTE_COUNT
     HIPCHK(c, hipGetLastError());
     // per-shard totals = differences of the shard start offsets
     uint32_t starts[65];
@@ -1931,6 +1981,29 @@ int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = starts[s + 1] - starts[s];
     return NKML_OK;
+}
+
+int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
+                           uint32_t *d_send_src, uint64_t *send_counts)
+{
+    if (!c || !d_keys || !d_send_keys || !d_send_src || !send_counts || n_shards == 0 || n_shards > 64) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return route_common(c, d_keys, n_keys, 0, n_shards, d_send_keys, d_send_src, send_counts);
+}
+
+int nkml_route_reads_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t n_shards,
+                            void *d_send_keys, uint32_t *d_send_src, uint64_t *send_counts)
+{
+    if (!c || !d_seq || !d_offsets || !d_send_keys || !d_send_src || !send_counts || n_shards == 0 || n_shards > 64) return NKML_E_ARG;
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = 0;
+    if (n_reads == 0) return NKML_OK;
+    if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+    if ((rc = route_common(c, nullptr, (n_bases + 15) / 16 * 16, n_bases, n_shards, d_send_keys, d_send_src, send_counts)) != NKML_OK) return rc;
+    if ((rc = fetch_counters(c)) != NKML_OK) return rc; // the stream has been waited for: the bad-base tally is final
+    return check_bad_bases(c);
 }
 
 int nkml_unroute_flags_device(nkml_ctx *c, const uint8_t *d_recv_flags, const uint32_t *d_send_src, uint64_t n_sent, uint8_t *d_flags,

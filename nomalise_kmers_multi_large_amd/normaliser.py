@@ -186,6 +186,11 @@ class KmerNormaliser:
         self._chk(self.lib.nkml_route_keys_device(self.h, d_keys, n_keys, n_shards, d_send_keys, d_send_src, counts))
         return [int(x) for x in counts]
 
+    def route_reads_device(self, d_seq, d_offsets, n_reads, n_bases, n_shards, d_send_keys, d_send_src):
+        counts = (ctypes.c_uint64 * n_shards)()
+        self._chk(self.lib.nkml_route_reads_device(self.h, d_seq, d_offsets, n_reads, n_bases, n_shards, d_send_keys, d_send_src, counts))
+        return [int(x) for x in counts]
+
     def unroute_flags_device(self, d_recv_flags, d_send_src, n_sent, d_flags, n_keys):
         self._chk(self.lib.nkml_unroute_flags_device(self.h, d_recv_flags, d_send_src, n_sent, d_flags, n_keys))
 

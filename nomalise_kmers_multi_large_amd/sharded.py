@@ -54,6 +54,14 @@ class HipShardEngine:
         n = sum(counts)
         return self.send_keys[:n], self.send_src[:n], counts
 
+    def kmerise_route(self, seq, offsets, n_reads, n_bases, n_shards):
+        """kmerise + route in one go: the k-mers are recomputed from the packed reads by the routing passes
+        themselves, no key array is written.  Returns (send_keys, send_src, counts, n_positions)."""
+        counts = self.nk.route_reads_device(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, n_shards,
+                                            self.send_keys.data_ptr(), self.send_src.data_ptr())
+        n = sum(counts)
+        return self.send_keys[:n], self.send_src[:n], counts, (n_bases + 15) // 16 * 16
+
     def recv_buffer(self, n):
         if n > self.cap:
             raise RuntimeError("received %d keys, more than the %d this rank was sized for" % (n, self.cap))
@@ -163,15 +171,19 @@ class ShardedNormaliser:
         """seq/offsets: this rank's reads (device tensors for the HIP engine).  Returns (high, total) of this
         rank's reads, and on rank 0 additionally the gathered (high_all, total_all) lists per rank."""
         eng, W = self.eng, self.world
-        keys = eng.kmerise(seq, offsets, n_reads, n_bases)
-        send_keys, send_src, send_counts = eng.route(keys, W)
+        if hasattr(eng, "kmerise_route"):
+            send_keys, send_src, send_counts, n_positions = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
+        else:
+            keys = eng.kmerise(seq, offsets, n_reads, n_bases)
+            send_keys, send_src, send_counts = eng.route(keys, W)
+            n_positions = keys.numel()
         recv_counts, peak = self._exchange_counts(send_counts, send_keys)
         recv_keys = eng.recv_buffer(sum(recv_counts))
         self._all_to_all(recv_keys, send_keys, recv_counts, send_counts, peak)
         recv_flags = eng.count(recv_keys)
         back = eng.back_buffer(sum(send_counts))
         self._all_to_all(back, recv_flags, send_counts, recv_counts, peak)
-        flags = eng.unroute(back, send_src, keys.numel())
+        flags = eng.unroute(back, send_src, n_positions)
         high, total = eng.reduce(flags, offsets, n_reads)
         gathered = None
         if self.gather_to_root:
