@@ -409,3 +409,68 @@ def test_known_answer_two_million_synthetic_pairs(nk, k, canonical, batch_pairs,
             kept += int(keep[: nr // 2].sum())
         assert kept == want_kept
         assert g.unique_kmers == want_unique
+
+
+def _two_rank_worker(rank, world, port, steps, bp, q):
+    import torch
+    import torch.distributed as dist
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.sharded import HipShardEngine, ShardedNormaliser
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, slack=2.0)
+        sn = ShardedNormaliser(eng, stage_through_host=True, max_message_bytes=4 << 20)
+        blocks = list(synth.pair_blocks(steps * bp, seed=11 + rank, transcripts=30, block=bp))
+        out = []
+        for c1, c2 in blocks:
+            seq, off = synth.interleave(c1, c2)
+            high, total, gathered = sn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq))
+            sn.synchronize()
+            if rank == 0:
+                out.append([g.cpu().numpy().copy() for g in gathered])
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_equal_single_table(nk):
+    """Two ranks with the product engine (each its own context and table shard on this GPU), exchanging over gloo
+    through host memory: the per-read counters gathered on rank 0 equal those of one table reading the global
+    stream (per step: rank 0's reads, then rank 1's)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from nomalise_kmers_multi_large_amd import synth
+    world, steps, bp = 2, 3, 15000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, steps, bp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    data = [list(synth.pair_blocks(steps * bp, seed=11 + r, transcripts=30, block=bp)) for r in range(world)]
+    with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
+        h = torch.zeros(2 * bp, dtype=torch.int32, device="cuda")
+        t = torch.zeros_like(h)
+        crossed = 0
+        for step in range(steps):
+            for r in range(world):
+                seq, off = synth.interleave(*data[r][step])
+                d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+                nr = len(off) - 1
+                g.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, len(seq), h.data_ptr(), t.data_ptr())
+                g.synchronize()
+                np.testing.assert_array_equal(got[step][r][0], h[:nr].cpu().numpy())
+                np.testing.assert_array_equal(got[step][r][1], t[:nr].cpu().numpy())
+                crossed += int(h[:nr].sum())
+        assert crossed > 0
