@@ -331,19 +331,6 @@ __global__ void __launch_bounds__(256) k_count_direct(const uint32_t *__restrict
     flush_tallies(uniq, counted, nsat, ctr);
 }
 
-// Seeding (sequence_to_hash_zero, normalise_kmers_multi_large.c:1501-1537): the key becomes present, its count
-// is left alone.
-__global__ void __launch_bounds__(256) k_seed_direct(const uint32_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ counts,
-                                                     Counters *ctr)
-{
-    uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint32_t uniq = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        uint32_t key = keys[i];
-        if (key && atomicOr(&counts[key], SEEDED_BIT) == 0) uniq++;
-    }
-    flush_tallies(uniq, 0, 0, ctr);
-}
 
 // K4a: right after a chunk's counting pass, collect the occurrences of the k-mers that crossed in it:
 // (id << posbits) | position-in-batch.  The filter screens, the count (>= depth, and the occurrence was not
@@ -514,21 +501,6 @@ __global__ void __launch_bounds__(256) k_count_hashed(const unsigned long long *
     flush_tallies(uniq, counted, nsat, ctr);
 }
 
-__global__ void __launch_bounds__(256) k_seed_hashed(const unsigned long long *__restrict__ keys, uint64_t n, Slot *__restrict__ slots,
-                                                     uint64_t cap_mask, Counters *ctr)
-{
-    uint64_t stride = (uint64_t)gridDim.x * 256;
-    uint32_t uniq = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        unsigned long long key = keys[i];
-        if (!key) continue;
-        bool inserted; uint32_t state;
-        uint64_t h = find_or_insert(slots, cap_mask, key, inserted, state);
-        if (h == ~0ull) atomicAdd(&ctr->probe_overflow, 1u);
-        else if (inserted) uniq++;
-    }
-    flush_tallies(uniq, 0, 0, ctr);
-}
 
 // read-only lookup: slot of a key that is known to be stored, ~0 if it is not
 __device__ __forceinline__ uint64_t find_slot(const Slot *__restrict__ slots, uint64_t cap_mask, unsigned long long key)
@@ -699,7 +671,7 @@ __global__ void __launch_bounds__(256) k_count_words_hashed(const uint32_t *__re
     flush_tallies(uniq, counted, nsat, ctr);
 }
 
-// seeding form (sequence_to_hash_zero): keys become present, counts are left alone
+// Seeding (sequence_to_hash_zero, normalise_kmers_multi_large.c:1501-1537): keys become present, counts are left alone
 template <bool CANON, bool DIRECT>
 __global__ void __launch_bounds__(256) k_seed_words(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
                                                     uint64_t n_bases, uint64_t n_words, int k, uint32_t *__restrict__ counts,
