@@ -1603,7 +1603,9 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     {
         // the partitioned path needs 30-bit codes, 7-bit saturating counts and no exact counts past depth; it pays
         // where a batch spreads over many 2^14-code buckets, i.e. at k = 15 (4^15 / 2^14 = 65536 buckets)
-        const bool can = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS);
+        // (and batches whose padded first-pass output still fits 32-bit positions)
+        const bool can = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS) &&
+                         cfg->max_batch_bases < (1ull << 32) - (4ull << 20);
         const char *env = getenv("NKML_PARTITIONED");
         bool want = cfg->ksize == 15;
         if (env && (env[0] == '0' || env[0] == '1')) want = env[0] == '1';
