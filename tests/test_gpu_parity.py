@@ -290,7 +290,8 @@ class partitioned_mode:
             os.environ["NKML_PARTITIONED"] = self.old
 
 
-@pytest.mark.parametrize("k,depth,canonical", [(5, 2, False), (7, 5, True), (9, 100, True), (13, 3, False), (15, 3, False), (15, 100, True)])
+@pytest.mark.parametrize("k,depth,canonical", [(5, 2, False), (7, 5, True), (9, 100, True), (9, 127, False), (13, 3, False), (15, 3, False),
+                                               (15, 100, True)])
 def test_partitioned_random_reads(nk, oracle_lib, k, depth, canonical):
     rng = np.random.default_rng(4000 + k * 7 + depth)
     reads = random_reads(rng, 600, k, 4 * k + 40, b"AC") + random_reads(rng, 600, k, 200, b"ACGT", 0.01) \

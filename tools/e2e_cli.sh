@@ -12,7 +12,7 @@ ls -la $d | tail -2
 cd $d
 for rep in 1 2; do
   export NKML_TIMING=1; t0=$(date +%s.%N)
-  $GRAFT_REPO_ROOT/nomalise_kmers_multi_large_amd/nkml_amd -f syn_1.fastq -r syn_2.fastq -k 15 -d 100 -g 0.9 > run$rep.log 2> err$rep.log; grep "host phases" err$rep.log
+  $GRAFT_REPO_ROOT/nomalise_kmers_multi_large_amd/nkml_amd -f syn_1.fastq -r syn_2.fastq ${NKML_E2E_ARGS:--k 15 -d 100 -g 0.9} > run$rep.log 2> err$rep.log; grep "host phases" err$rep.log
   t1=$(date +%s.%N)
   grep -i "rate\|Printed Records\|Skipped Records\|unique\|runtime" run$rep.log | tail -8
   python3 -c "print('nkml_amd wall %.2f s -> %.2f M pairs/s file to file' % ($t1 - $t0, $n / ($t1 - $t0) / 1e6))"
