@@ -71,8 +71,9 @@ typedef struct nkml_config {
 #define NKML_F_COUNT_PARTITIONED 8u /* count by radix-partitioning each batch's k-mers into 2^14-code buckets that are
                                   counted in LDS against a 1-byte-per-k-mer table, wherever that path can run
                                   (k <= 15, depth <= 127, no NKML_F_EXACT_COUNTS).  With neither flag the library
-                                  chooses: partitioned at k = 15, atomics otherwise; the environment variable
-                                  NKML_PARTITIONED=0/1 overrides that choice.  Results are identical either way. */
+                                  chooses: partitioned at k = 15 and, for batches up to about 2 M pairs of 150 bases,
+                                  at k = 14; atomics otherwise; the environment variable NKML_PARTITIONED=0/1
+                                  overrides that choice.  Results are identical either way. */
 
 typedef struct nkml_stats {
     uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */

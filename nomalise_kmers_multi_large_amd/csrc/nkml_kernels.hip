@@ -1602,12 +1602,15 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     c->direct = cfg->ksize <= 16;
     {
         // the partitioned path needs 30-bit codes, 7-bit saturating counts and no exact counts past depth; it pays
-        // where a batch spreads over many 2^14-code buckets, i.e. at k = 15 (4^15 / 2^14 = 65536 buckets)
+        // where a batch spreads over many 2^14-code buckets (4^15 / 2^14 = 65536 at k = 15)
         // (and batches whose padded first-pass output still fits 32-bit positions)
         const bool can = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS) &&
                          cfg->max_batch_bases < (1ull << 32) - (4ull << 20);
         const char *env = getenv("NKML_PARTITIONED");
-        bool want = cfg->ksize == 15;
+        // chosen by default where a full batch leaves the buckets well inside the fast bucket kernel's reach
+        // (fewer than 65535 keys each): k = 15 always, k = 14 up to about 2 M pairs of 150 bases per batch
+        const uint64_t buckets = (1ull << (2 * cfg->ksize)) >> 14;
+        bool want = cfg->ksize >= 14 && cfg->ksize <= 15 && cfg->max_batch_bases / buckets <= 40000;
         if (env && (env[0] == '0' || env[0] == '1')) want = env[0] == '1';
         if (cfg->flags & NKML_F_COUNT_PARTITIONED) want = true;
         if (cfg->flags & NKML_F_COUNT_ATOMIC) want = false;
