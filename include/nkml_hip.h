@@ -112,14 +112,20 @@ int nkml_get_stats(nkml_ctx *ctx, nkml_stats *out);
 
 /* Host-buffer path (what the command-line host uses): reads concatenated in `seq`, read i occupies
  * [offsets[i], offsets[i+1]); mates of a pair are consecutive reads (forward first, ref:1559-1563).
- * submit stages the batch with hipMemcpyAsync and enqueues the kernels; collect waits and returns the
- * per-read counters in submission order.  Batch form of process_sequence_pair/_single (ref:1551, 1539). */
+ * submit stages the batch with hipMemcpyAsync and enqueues the kernels (on the partitioned path it returns without
+ * waiting for the device, so the caller can work while the batch is counted; the atomic path waits once inside
+ * submit); collect waits, reports a bad base (NKML_E_BADBASE) if the batch held one, and returns the per-read
+ * counters in submission order.  Batch form of process_sequence_pair/_single (ref:1551, 1539). */
 int nkml_submit(nkml_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
 int nkml_collect(nkml_ctx *ctx, int32_t *high, int32_t *total);
 /* The context's own pinned staging area (max_batch_bases bytes, max_batch_reads + 1 offsets): a caller that
  * builds its batch there and passes these pointers to nkml_submit / nkml_seed saves one copy of the batch.
  * No counterpart in the reference (its records are counted where read_line left them, ref:1605-1629). */
 int nkml_host_staging(nkml_ctx *ctx, uint8_t **seq, uint64_t **offsets);
+/* Waits until the last submitted / seeded batch has left the staging area for the device (not for its kernels):
+ * from then on the area may be filled with the next batch while the GPU is still counting.  No counterpart in the
+ * reference. */
+int nkml_wait_staged(nkml_ctx *ctx);
 
 /* Device-buffer path: the same batch already resident in HBM; d_high/d_total are device arrays of n_reads.
  * Asynchronous on the context's stream. */

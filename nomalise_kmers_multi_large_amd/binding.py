@@ -15,7 +15,7 @@ FLAG_NONE, FLAG_HIGH, FLAG_LOW = 0, 1, 2
 
 # every symbol include/nkml_hip.h declares
 EXPORTS = [
-    "nkml_abi_version", "nkml_strerror", "nkml_last_error", "nkml_create", "nkml_destroy", "nkml_reset", "nkml_host_staging",
+    "nkml_abi_version", "nkml_strerror", "nkml_last_error", "nkml_create", "nkml_destroy", "nkml_reset", "nkml_host_staging", "nkml_wait_staged",
     "nkml_set_stream", "nkml_synchronize", "nkml_get_stats", "nkml_submit", "nkml_collect", "nkml_process_device",
     "nkml_seed", "nkml_keep_pair", "nkml_keep_single", "nkml_decide_device", "nkml_key_bytes", "nkml_kmerise_device",
     "nkml_count_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_reads_device",

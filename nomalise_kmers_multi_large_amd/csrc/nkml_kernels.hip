@@ -1081,6 +1081,9 @@ struct nkml_ctx {
     int32_t *h_high, *h_total;
     uint32_t pending_reads; // reads of the submitted, not yet collected batch
     bool pending;
+    bool pending_check; // the submitted batch's counters / bad-base tally have not been looked at yet
+    hipEvent_t ev_staged; // after the host-to-device copies of the last staged batch
+    bool staged_pending;
 
     // stats
     uint64_t crossing_kmers, crossing_occ;
@@ -1645,6 +1648,7 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     c->own_stream = true;
     if (cfg->flags & NKML_F_PROFILE)
         for (int i = 0; i < 2 * 64; i++) CREATE_HIP(hipEventCreate(&c->ev[i]));
+    CREATE_HIP(hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
     CREATE_HIP(hipMalloc(&c->d_ctr, sizeof(Counters)));
     CREATE_HIP(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
     memset(c->h_ctr, 0, sizeof(Counters));
@@ -1700,6 +1704,7 @@ void nkml_destroy(nkml_ctx *c)
     if (c->h_total) hipHostFree(c->h_total);
     for (int i = 0; i < 2 * 64; i++)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->ev_staged) hipEventDestroy(c->ev_staged);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1784,8 +1789,10 @@ int nkml_reduce_reads_device(nkml_ctx *c, const void *d_keys, const uint8_t *d_f
     return run_reduce(c, d_flags, d_offsets, n_reads, d_high, d_total);
 }
 
-int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
-                        int32_t *d_high, int32_t *d_total)
+// defer_check (partitioned path only): nothing here waits for the device; the caller fetches the counters and looks
+// at the bad-base tally once it has waited for the stream (nkml_collect)
+static int process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
+                          int32_t *d_high, int32_t *d_total, bool defer_check)
 {
     if (!c || !d_seq || !d_offsets || !d_high || !d_total) return NKML_E_ARG;
     int rc = check_batch(c, n_reads, n_bases);
@@ -1797,6 +1804,7 @@ int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_off
         if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
         if ((rc = run_count_partitioned(c, nullptr, n_keys, n_bases, nullptr, false)) != NKML_OK) return rc;
         if ((rc = run_reduce_words(c, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
+        if (defer_check) { c->pending_check = true; return NKML_OK; }
         if ((rc = fetch_counters(c)) != NKML_OK) return rc; // bad-base tally; the one wait of the batch
         if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
         return check_bad_bases(c);
@@ -1805,6 +1813,12 @@ int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_off
     if ((rc = run_fused(c, n_bases, false)) != NKML_OK) return rc;
     if ((rc = check_bad_bases(c)) != NKML_OK) return rc;
     return run_reduce_words(c, d_offsets, n_reads, d_high, d_total);
+}
+
+int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
+                        int32_t *d_high, int32_t *d_total)
+{
+    return process_device(c, d_seq, d_offsets, n_reads, n_bases, d_high, d_total, false);
 }
 
 static int stage_host_batch(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads, uint64_t *n_bases_out)
@@ -1824,7 +1838,19 @@ static int stage_host_batch(nkml_ctx *c, const uint8_t *seq, const uint64_t *off
     if (offsets != c->h_offsets) memcpy(c->h_offsets, offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t));
     HIPCHK(c, hipMemcpyAsync(c->d_seq, c->h_seq, n_bases, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_offsets, c->h_offsets, ((uint64_t)n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_staged, c->stream));
+    c->staged_pending = true;
     *n_bases_out = n_bases;
+    return NKML_OK;
+}
+
+int nkml_wait_staged(nkml_ctx *c)
+{
+    if (!c) return NKML_E_ARG;
+    if (c->staged_pending) {
+        HIPCHK(c, hipEventSynchronize(c->ev_staged));
+        c->staged_pending = false;
+    }
     return NKML_OK;
 }
 
@@ -1844,7 +1870,7 @@ int nkml_submit(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32
     uint64_t n_bases = 0;
     int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
     if (rc != NKML_OK) return rc;
-    if ((rc = nkml_process_device(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->d_high, c->d_total)) != NKML_OK) return rc;
+    if ((rc = process_device(c, c->d_seq, c->d_offsets, n_reads, n_bases, c->d_high, c->d_total, true)) != NKML_OK) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_high, c->d_high, (uint64_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_total, c->d_total, (uint64_t)n_reads * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     c->pending = true;
@@ -1857,9 +1883,16 @@ int nkml_collect(nkml_ctx *c, int32_t *high, int32_t *total)
     if (!c || !high || !total) return NKML_E_ARG;
     if (!c->pending) return fail(c, NKML_E_STATE, "nothing submitted");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    if (c->pending_check) { // the partitioned path left its end-of-batch checks to this wait
+        c->pending_check = false;
+        int rc = fetch_counters(c);
+        if (rc != NKML_OK) return rc;
+        if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
+        if ((rc = check_bad_bases(c)) != NKML_OK) return rc;
+    }
     memcpy(high, c->h_high, (uint64_t)c->pending_reads * sizeof(int32_t));
     memcpy(total, c->h_total, (uint64_t)c->pending_reads * sizeof(int32_t));
-    c->pending = false;
     return NKML_OK;
 }
 

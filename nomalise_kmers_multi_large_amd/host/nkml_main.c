@@ -341,22 +341,27 @@ static void build_index(struct findex *fi, const char *base, size_t size, bool a
 struct batch {
     uint8_t *seq;       /* pinned staging of the library (nkml_host_staging) */
     uint64_t *offsets;
-    uint32_t *rec;      /* per unit (pair or single read): its record number in the window */
-    int32_t *high, *total;
-    uint8_t *use;       /* per record of the window: long enough to be counted (ref:1630-1631) */
-    uint32_t n_reads, n_units;
-    uint64_t n_bases;
     uint32_t cap_reads;
     uint64_t cap_bases;
+};
+
+/* One window of the input: its line index, its records and their results.  Two of them alternate, so that the kept
+ * records of one window are formatted and written while the GPU counts the next one. */
+struct window {
+    struct findex F, R;
+    size_t n_rec;       /* records taken from the window */
+    uint8_t *use;       /* per record: long enough to be counted (ref:1630-1631) */
     size_t cap_use;
+    uint32_t *rec;      /* per unit (pair or single read): its record number in the window */
+    int32_t *high, *total;
+    uint32_t n_reads, n_units;
+    uint64_t n_bases;
 };
 
 struct plan {
-    struct findex F, R;
     bool paired, to_fasta;
     int lines;
     uint32_t K;
-    size_t n_rec;
     /* sizing pass, per thread */
     size_t t_units[MAX_THREADS], t_bases[MAX_THREADS], t_bad[MAX_THREADS];
     int t_bad_rev[MAX_THREADS], long_line;
@@ -367,6 +372,7 @@ struct plan {
 
 static struct batch B;
 static struct plan P;
+static struct window WIN[2], *W = &WIN[0]; /* W: the window the running phase works on */
 
 /* NKML_TIMING=1: wall time of each phase of the host pipeline on stderr at exit */
 static int timing_on;
@@ -397,10 +403,12 @@ static void batch_alloc(uint32_t cap_reads, uint64_t cap_bases)
     B.cap_bases = cap_bases;
     int rc = nkml_host_staging(ctx, &B.seq, &B.offsets);
     if (rc != NKML_OK) die_nkml("staging", rc);
-    B.rec = malloc((size_t)cap_reads * sizeof(uint32_t));
-    B.high = malloc((size_t)cap_reads * sizeof(int32_t));
-    B.total = malloc((size_t)cap_reads * sizeof(int32_t));
-    if (!B.rec || !B.high || !B.total) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    for (int w = 0; w < 2; w++) {
+        WIN[w].rec = malloc((size_t)cap_reads * sizeof(uint32_t));
+        WIN[w].high = malloc((size_t)cap_reads * sizeof(int32_t));
+        WIN[w].total = malloc((size_t)cap_reads * sizeof(int32_t));
+        if (!WIN[w].rec || !WIN[w].high || !WIN[w].total) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    }
     B.offsets[0] = 0;
 }
 
@@ -431,20 +439,20 @@ static void size_records(int tid, int nt, void *arg)
 {
     (void)arg;
     size_t a, b;
-    rec_range(P.n_rec, tid, nt, &a, &b);
+    rec_range(W->n_rec, tid, nt, &a, &b);
     size_t units = 0, bases = 0;
     P.t_bad[tid] = SIZE_MAX;
     for (size_t i = a; i < b; i++) {
         for (int l = 0; l < P.lines; l++) {
             const size_t g = i * (size_t)P.lines + (size_t)l;
-            if (line_end(&P.F, g) - line_start(&P.F, g) > MAX_LINE) P.long_line = 1;
-            if (P.paired && line_end(&P.R, g) - line_start(&P.R, g) > MAX_LINE) P.long_line = 1;
+            if (line_end(&W->F, g) - line_start(&W->F, g) > MAX_LINE) P.long_line = 1;
+            if (P.paired && line_end(&W->R, g) - line_start(&W->R, g) > MAX_LINE) P.long_line = 1;
         }
         uint32_t lf, lr = 0;
-        const char *sf = seq_line(&P.F, P.lines, i, &lf);
-        const char *sr = P.paired ? seq_line(&P.R, P.lines, i, &lr) : NULL;
+        const char *sf = seq_line(&W->F, P.lines, i, &lf);
+        const char *sr = P.paired ? seq_line(&W->R, P.lines, i, &lr) : NULL;
         const bool long_enough = lf >= P.K && (!P.paired || lr >= P.K);
-        B.use[i] = long_enough;
+        W->use[i] = long_enough;
         if (!long_enough) continue; /* dropped without being counted anywhere, ref:1630-1631 */
         if (lf > MAX_LINE || lr > MAX_LINE) continue; /* reported after the phase */
         if (!valid_bases(sf, lf)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 0; break; }
@@ -461,17 +469,17 @@ static void stage_records(int tid, int nt, void *arg)
 {
     (void)arg;
     size_t a, b;
-    rec_range(P.n_rec, tid, nt, &a, &b);
+    rec_range(W->n_rec, tid, nt, &a, &b);
     size_t u = 0, at = 0;
     for (int t = 0; t < tid; t++) { u += P.t_units[t]; at += P.t_bases[t]; }
     const size_t u_end = u + P.t_units[tid];
     for (size_t i = a; i < b && u < u_end; i++) {
-        if (!B.use[i]) continue;
+        if (!W->use[i]) continue;
         uint32_t lf, lr = 0;
-        const char *sf = seq_line(&P.F, P.lines, i, &lf);
-        B.rec[u] = (uint32_t)i;
+        const char *sf = seq_line(&W->F, P.lines, i, &lf);
+        W->rec[u] = (uint32_t)i;
         if (P.paired) {
-            const char *sr = seq_line(&P.R, P.lines, i, &lr);
+            const char *sr = seq_line(&W->R, P.lines, i, &lr);
             memcpy(B.seq + at, sf, lf);
             B.offsets[2 * u + 1] = at + lf;
             memcpy(B.seq + at + lf, sr, lr);
@@ -520,8 +528,8 @@ static char *put_record(char *o, const struct findex *fi, size_t i, int lines, b
 
 static inline bool keep_unit(uint32_t u)
 {
-    if (P.paired) return nkml_keep_pair(B.high[2 * u], B.total[2 * u], B.high[2 * u + 1], B.total[2 * u + 1], cfg.coverage) != 0; /* ref:1646 */
-    return nkml_keep_single(B.high[u], B.total[u], cfg.coverage) != 0;                                                             /* ref:1992 */
+    if (P.paired) return nkml_keep_pair(W->high[2 * u], W->total[2 * u], W->high[2 * u + 1], W->total[2 * u + 1], cfg.coverage) != 0; /* ref:1646 */
+    return nkml_keep_single(W->high[u], W->total[u], cfg.coverage) != 0;                                                             /* ref:1992 */
 }
 
 /* Phase 3: decisions and the bytes of the kept records, per thread into its own buffer (written out in thread order) */
@@ -529,7 +537,7 @@ static void format_records(int tid, int nt, void *arg)
 {
     (void)arg;
     size_t a, b;
-    rec_range(B.n_units, tid, nt, &a, &b);
+    rec_range(W->n_units, tid, nt, &a, &b);
     P.olen[0][tid] = P.olen[1][tid] = 0;
     P.t_printed[tid] = 0;
     if (a == b) return;
@@ -537,8 +545,8 @@ static void format_records(int tid, int nt, void *arg)
     const bool write_f = P.paired || !P.to_fasta, write_r = P.paired;
     for (int f = 0; f < 2; f++) {
         if (!(f == 0 ? write_f : write_r)) continue;
-        const struct findex *fi = f == 0 ? &P.F : &P.R;
-        const size_t first = (size_t)B.rec[a] * (size_t)P.lines, last = (size_t)B.rec[b - 1] * (size_t)P.lines + (size_t)P.lines - 1;
+        const struct findex *fi = f == 0 ? &W->F : &W->R;
+        const size_t first = (size_t)W->rec[a] * (size_t)P.lines, last = (size_t)W->rec[b - 1] * (size_t)P.lines + (size_t)P.lines - 1;
         const size_t need = line_end(fi, last) - line_start(fi, first) + 4 * (b - a) + 64;
         if (need > P.ocap[f][tid]) {
             free(P.obuf[f][tid]);
@@ -552,8 +560,8 @@ static void format_records(int tid, int nt, void *arg)
     for (size_t u = a; u < b; u++) {
         if (!keep_unit((uint32_t)u)) continue;
         printed++;
-        if (write_f) of = put_record(of, &P.F, B.rec[u], P.lines, P.to_fasta, true);
-        if (write_r) orv = put_record(orv, &P.R, B.rec[u], P.lines, P.to_fasta, false);
+        if (write_f) of = put_record(of, &W->F, W->rec[u], P.lines, P.to_fasta, true);
+        if (write_r) orv = put_record(orv, &W->R, W->rec[u], P.lines, P.to_fasta, false);
     }
     P.olen[0][tid] = write_f ? (size_t)(of - P.obuf[0][tid]) : 0;
     P.olen[1][tid] = write_r ? (size_t)(orv - P.obuf[1][tid]) : 0;
@@ -579,17 +587,31 @@ static void write_records(int tid, int nt, void *arg)
     }
 }
 
-/* Count the staged batch on the GPU, then decide and write in input order. */
-static void flush_batch(void)
+/* The staged window goes to the GPU; on the partitioned counting path the call returns at once. */
+static void submit_window(void)
 {
-    if (B.n_units == 0) return;
+    if (W->n_units == 0) return;
     int rc = 0;
     TIMED(3, {
-        rc = nkml_submit(ctx, B.seq, B.offsets, B.n_reads);
+        rc = nkml_submit(ctx, B.seq, B.offsets, W->n_reads);
         if (rc != NKML_OK) die_nkml("submit", rc);
-        rc = nkml_collect(ctx, B.high, B.total);
+    });
+}
+
+/* Wait for the window's counters, then decide and write in input order. */
+static void finish_window(void)
+{
+    if (W->n_units == 0) return;
+    int rc = 0;
+    TIMED(3, {
+        rc = nkml_collect(ctx, W->high, W->total);
         if (rc != NKML_OK) die_nkml("collect", rc);
     });
+}
+
+static void write_window(void)
+{
+    if (W->n_units == 0) return;
     TIMED(4, parallel_run(format_records, NULL));
     TIMED(5, {
         parallel_run(write_records, NULL);
@@ -599,14 +621,14 @@ static void flush_batch(void)
         }
     });
     if (cfg.debug > 1) {
-        for (uint32_t u = 0; u < B.n_units; u++) {
+        for (uint32_t u = 0; u < W->n_units; u++) {
             const bool keep = keep_unit(u);
             if (P.paired) { /* ref:1677-1692 */
-                int32_t hf = B.high[2 * u], tf = B.total[2 * u], hr = B.high[2 * u + 1], tr = B.total[2 * u + 1];
+                int32_t hf = W->high[2 * u], tf = W->total[2 * u], hr = W->high[2 * u + 1], tr = W->total[2 * u + 1];
                 printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d;R:%d, Total kmers: F:%d;R:%d High count ratio: F:%.2f;R:%.2f\n",
                        tot.processed + u + 1, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, hr, tf, tr, ratio_f32(hf, tf), ratio_f32(hr, tr));
             } else { /* ref:2017-2032 */
-                int32_t hf = B.high[u], tf = B.total[u];
+                int32_t hf = W->high[u], tf = W->total[u];
                 printf("Thread 0 - Sequence pair %'zu %s: High (%d) count kmers: F:%d, Total kmers: F:%d High count ratio: F:%.2f\n",
                        tot.processed + u + 1, keep ? "PRINTED" : "SKIPPED", cfg.depth, hf, tf, ratio_f32(hf, tf));
             }
@@ -614,89 +636,113 @@ static void flush_batch(void)
     }
     size_t printed = 0;
     for (int t = 0; t < n_threads; t++) printed += P.t_printed[t];
-    tot.processed += B.n_units;
+    tot.processed += W->n_units;
     tot.printed += printed;
-    tot.skipped += B.n_units - printed;
-    B.n_reads = B.n_units = 0;
-    B.n_bases = 0;
+    tot.skipped += W->n_units - printed;
+    W->n_reads = W->n_units = 0;
+    W->n_bases = 0;
+}
+
+/* Index and size the next window of the file (pair) into *W.  Returns false when no record (pair) is left.
+ * *bad / *bad_rev: the record at which the run has to stop with the reference's fatal message (SIZE_MAX: none). */
+static bool size_window(const struct mapped *fwd, const struct mapped *rev, size_t *pos_f, size_t *pos_r, size_t *bytes_per_rec,
+                        size_t *bad, int *bad_rev)
+{
+    const size_t cap_units = P.paired ? B.cap_reads / 2 : B.cap_reads;
+    size_t want = cap_units * *bytes_per_rec;
+    if (want > (size_t)3 << 30) want = (size_t)3 << 30; /* line offsets are 32-bit */
+    size_t wf = fwd->size - *pos_f < want ? fwd->size - *pos_f : want;
+    TIMED(0, build_index(&W->F, fwd->data + *pos_f, wf, *pos_f + wf == fwd->size));
+    size_t n_rec = W->F.n_lines / (size_t)P.lines;
+    if (P.paired) {
+        size_t wr = rev->size - *pos_r < want ? rev->size - *pos_r : want;
+        TIMED(0, build_index(&W->R, rev->data + *pos_r, wr, *pos_r + wr == rev->size));
+        if (W->R.n_lines / (size_t)P.lines < n_rec) n_rec = W->R.n_lines / (size_t)P.lines;
+    }
+    if (n_rec > cap_units) n_rec = cap_units;
+    if (n_rec == 0) return false; /* fewer lines left than one record (pair): the loop of ref:1605 ends */
+    if (n_rec > W->cap_use) {
+        free(W->use);
+        W->cap_use = n_rec + n_rec / 8;
+        W->use = malloc(W->cap_use);
+        if (!W->use) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    }
+    for (;;) {
+        W->n_rec = n_rec;
+        P.long_line = 0;
+        TIMED(1, parallel_run(size_records, NULL));
+        if (P.long_line) {
+            fprintf(stderr, "FATAL: input line longer than %d bytes\n", MAX_LINE);
+            exit(EXIT_FAILURE);
+        }
+        *bad = SIZE_MAX;
+        for (int t = 0; t < n_threads; t++)
+            if (P.t_bad[t] < *bad) { *bad = P.t_bad[t]; *bad_rev = P.t_bad_rev[t]; }
+        size_t units = 0, bases = 0;
+        for (int t = 0; t < n_threads; t++) {
+            size_t a, b;
+            rec_range(n_rec, t, n_threads, &a, &b);
+            if (a > *bad) P.t_units[t] = P.t_bases[t] = 0; /* beyond the record the run stops at */
+            units += P.t_units[t];
+            bases += P.t_bases[t];
+        }
+        if (bases <= B.cap_bases) { W->n_units = (uint32_t)units; W->n_bases = bases; break; }
+        n_rec = (size_t)((double)n_rec * (double)B.cap_bases / (double)bases * 0.98); /* too many bases for one batch */
+        if (n_rec == 0) n_rec = 1;
+    }
+    W->n_reads = P.paired ? 2 * W->n_units : W->n_units;
+    /* on to the byte after the last record taken */
+    const size_t last = n_rec * (size_t)P.lines - 1;
+    const size_t used_f = line_end(&W->F, last) + (last < W->F.n_nl ? 1 : 0);
+    *pos_f += used_f;
+    *bytes_per_rec = used_f / n_rec + 64;
+    if (P.paired) {
+        const size_t used_r = line_end(&W->R, last) + (last < W->R.n_nl ? 1 : 0);
+        *pos_r += used_r;
+        if (used_r / n_rec + 64 > *bytes_per_rec) *bytes_per_rec = used_r / n_rec + 64;
+    }
+    return true;
 }
 
 /* The record loop of process_thread_chunk_paired / _single (ref:1568-1770, 1921-2111) for one file (pair):
- * window after window, each a whole number of records that fits one GPU batch. */
+ * window after window, each a whole number of records that fits one GPU batch.  While the GPU counts window i the
+ * host indexes and sizes window i+1, and once window i+1 has been handed over, formats and writes window i. */
 static void process_files(const struct mapped *fwd, const struct mapped *rev)
 {
     P.lines = cfg.fastq_in ? 4 : 2;
     P.paired = rev != NULL;
     P.to_fasta = cfg.fastq_in && !cfg.fastq_out;
     P.K = (uint32_t)cfg.ksize;
-    const size_t cap_units = P.paired ? B.cap_reads / 2 : B.cap_reads;
     size_t pos_f = 0, pos_r = 0;
     size_t bytes_per_rec = 512; /* window size guess; follows the data */
+    struct window *prev = NULL;
+    W = &WIN[0];
     for (;;) {
-        size_t want = cap_units * bytes_per_rec;
-        if (want > (size_t)3 << 30) want = (size_t)3 << 30; /* line offsets are 32-bit */
-        size_t wf = fwd->size - pos_f < want ? fwd->size - pos_f : want;
-        TIMED(0, build_index(&P.F, fwd->data + pos_f, wf, pos_f + wf == fwd->size));
-        size_t n_rec = P.F.n_lines / (size_t)P.lines;
-        size_t wr = 0;
-        if (P.paired) {
-            wr = rev->size - pos_r < want ? rev->size - pos_r : want;
-            TIMED(0, build_index(&P.R, rev->data + pos_r, wr, pos_r + wr == rev->size));
-            if (P.R.n_lines / (size_t)P.lines < n_rec) n_rec = P.R.n_lines / (size_t)P.lines;
-        }
-        if (n_rec > cap_units) n_rec = cap_units;
-        if (n_rec == 0) break; /* fewer lines left than one record (pair): the loop of ref:1605 ends */
-        if (n_rec > B.cap_use) {
-            free(B.use);
-            B.cap_use = n_rec + n_rec / 8;
-            B.use = malloc(B.cap_use);
-            if (!B.use) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
-        }
+        struct window *cur = W;
         size_t bad = SIZE_MAX;
         int bad_rev = 0;
-        for (;;) {
-            P.n_rec = n_rec;
-            P.long_line = 0;
-            TIMED(1, parallel_run(size_records, NULL));
-            if (P.long_line) {
-                fprintf(stderr, "FATAL: input line longer than %d bytes\n", MAX_LINE);
-                exit(EXIT_FAILURE);
-            }
-            bad = SIZE_MAX;
-            for (int t = 0; t < n_threads; t++)
-                if (P.t_bad[t] < bad) { bad = P.t_bad[t]; bad_rev = P.t_bad_rev[t]; }
-            size_t units = 0, bases = 0;
-            for (int t = 0; t < n_threads; t++) {
-                size_t a, b;
-                rec_range(n_rec, t, n_threads, &a, &b);
-                if (a > bad) P.t_units[t] = P.t_bases[t] = 0; /* beyond the record the run stops at */
-                units += P.t_units[t];
-                bases += P.t_bases[t];
-            }
-            if (bases <= B.cap_bases) { B.n_units = (uint32_t)units; B.n_bases = bases; break; }
-            n_rec = (size_t)((double)n_rec * (double)B.cap_bases / (double)bases * 0.98); /* too many bases for one batch */
-            if (n_rec == 0) n_rec = 1;
+        const bool more = size_window(fwd, rev, &pos_f, &pos_r, &bytes_per_rec, &bad, &bad_rev);
+        if (more) {
+            /* the staging area is the library's: the previous window's copy to the device has to be over */
+            if (prev) { int rc = nkml_wait_staged(ctx); if (rc != NKML_OK) die_nkml("wait", rc); }
+            TIMED(2, parallel_run(stage_records, NULL));
         }
-        B.n_reads = P.paired ? 2 * B.n_units : B.n_units;
-        TIMED(2, parallel_run(stage_records, NULL));
-        flush_batch();
-        if (bad != SIZE_MAX) {
+        if (prev) { W = prev; finish_window(); W = cur; }
+        if (more) submit_window();
+        if (prev) { W = prev; write_window(); W = cur; }
+        if (!more) break;
+        if (bad != SIZE_MAX) { /* everything before the bad record is counted and written, then the reference's exit */
+            finish_window();
+            write_window();
             uint32_t len;
-            const char *sq = seq_line(bad_rev ? &P.R : &P.F, P.lines, bad, &len);
+            const char *sq = seq_line(bad_rev ? &W->R : &W->F, P.lines, bad, &len);
             fatal_sequence(bad_rev ? "REV" : "FWD", sq, len);
             exit(EXIT_FAILURE);
         }
-        /* on to the byte after the last record taken */
-        const size_t last = n_rec * (size_t)P.lines - 1;
-        const size_t used_f = line_end(&P.F, last) + (last < P.F.n_nl ? 1 : 0);
-        pos_f += used_f;
-        bytes_per_rec = used_f / n_rec + 64;
-        if (P.paired) {
-            const size_t used_r = line_end(&P.R, last) + (last < P.R.n_nl ? 1 : 0);
-            pos_r += used_r;
-            if (used_r / n_rec + 64 > bytes_per_rec) bytes_per_rec = used_r / n_rec + 64;
-        }
+        prev = cur;
+        W = cur == &WIN[0] ? &WIN[1] : &WIN[0];
     }
+    W = &WIN[0];
 }
 
 /* seed_kmer_hash, ref:1322-1373: the first `limit` records whose sequence line is longer than k, of one file,
@@ -717,19 +763,19 @@ static void seed_file(const char *name, int limit)
         size_t want = (size_t)B.cap_reads * bytes_per_rec;
         if (want > (size_t)3 << 30) want = (size_t)3 << 30;
         const size_t w = size - pos < want ? size - pos : want;
-        build_index(&P.F, m.data + pos, w, false);
-        size_t n_rec = P.F.n_lines / (size_t)P.lines;
+        build_index(&W->F, m.data + pos, w, false);
+        size_t n_rec = W->F.n_lines / (size_t)P.lines;
         if (n_rec > B.cap_reads) n_rec = B.cap_reads;
         if (n_rec == 0) break;
-        if (n_rec > B.cap_use) {
-            free(B.use);
-            B.cap_use = n_rec + n_rec / 8;
-            B.use = malloc(B.cap_use);
-            if (!B.use) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+        if (n_rec > W->cap_use) {
+            free(W->use);
+            W->cap_use = n_rec + n_rec / 8;
+            W->use = malloc(W->cap_use);
+            if (!W->use) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
         }
         size_t units, bases;
         for (;;) {
-            P.n_rec = n_rec;
+            W->n_rec = n_rec;
             P.long_line = 0;
             parallel_run(size_records, NULL);
             if (P.long_line) {
@@ -748,7 +794,7 @@ static void seed_file(const char *name, int limit)
                 if (units + P.t_units[t] > (size_t)limit - done) {
                     size_t have = units;
                     for (size_t i = a; i < e; i++)
-                        if (B.use[i] && ++have == (size_t)limit - done) { cut = i; break; }
+                        if (W->use[i] && ++have == (size_t)limit - done) { cut = i; break; }
                 }
                 units += P.t_units[t];
                 bases += P.t_bases[t];
@@ -756,7 +802,7 @@ static void seed_file(const char *name, int limit)
             if (cut != SIZE_MAX && cut + 1 < n_rec) { n_rec = cut + 1; continue; } /* only the records up to the limit */
             if (bad != SIZE_MAX) { /* a record the reference would have stopped at before reaching the limit */
                 uint32_t len;
-                const char *sq = seq_line(&P.F, P.lines, bad, &len);
+                const char *sq = seq_line(&W->F, P.lines, bad, &len);
                 fatal_sequence("FWD", sq, len);
                 exit(EXIT_FAILURE);
             }
@@ -764,18 +810,18 @@ static void seed_file(const char *name, int limit)
             n_rec = (size_t)((double)n_rec * (double)B.cap_bases / (double)bases * 0.98);
             if (n_rec == 0) n_rec = 1;
         }
-        B.n_units = B.n_reads = (uint32_t)units;
-        B.n_bases = bases;
+        W->n_units = W->n_reads = (uint32_t)units;
+        W->n_bases = bases;
         if (units) {
             parallel_run(stage_records, NULL);
-            int rc = nkml_seed(ctx, B.seq, B.offsets, B.n_reads);
+            int rc = nkml_seed(ctx, B.seq, B.offsets, W->n_reads);
             if (rc != NKML_OK) die_nkml("seed", rc);
         }
         done += units;
-        B.n_reads = B.n_units = 0;
-        B.n_bases = 0;
+        W->n_reads = W->n_units = 0;
+        W->n_bases = 0;
         const size_t last = n_rec * (size_t)P.lines - 1;
-        const size_t used = line_end(&P.F, last) + 1;
+        const size_t used = line_end(&W->F, last) + 1;
         pos += used;
         bytes_per_rec = used / n_rec + 64;
     }
