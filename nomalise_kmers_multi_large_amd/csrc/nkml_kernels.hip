@@ -1040,8 +1040,7 @@ struct nkml_ctx {
     uint32_t *pt_keys, *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
     uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
-    uint16_t *pt_keysB, *pt_sposA, *pt_sposB; // spos / sdig: what the forward passes leave for the reverse passes
-    uint8_t *pt_sdigA, *pt_sdigB;
+    uint16_t *pt_keysB, *pt_sposA, *pt_sposB; // spos: what the forward passes leave for the reverse passes
     uint8_t *pt_flags, *pt_flagsA, *pt_flagsB;
     uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
     uint64_t pt_timed_keys;
@@ -1144,9 +1143,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
         HIPCHK(c, hipMalloc(&c->pt_flagsB, npos));
         HIPCHK(c, hipMalloc(&c->pt_sposA, c->pt_tiles_a * PT_TILE * sizeof(uint16_t)));
-        HIPCHK(c, hipMalloc(&c->pt_sdigA, c->pt_tiles_a * PT_TILE));
         HIPCHK(c, hipMalloc(&c->pt_sposB, na * sizeof(uint16_t)));
-        HIPCHK(c, hipMalloc(&c->pt_sdigB, na));
         // histograms and their scans: one row of 256 per tile plus the all-zero row after the last tile
         HIPCHK(c, hipMalloc(&c->pt_histA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_scanA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
@@ -1463,7 +1460,6 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     const uint64_t n_words = n / 16;
     const int k = c->cfg.ksize;
     uint16_t *spos_a = seeding ? nullptr : c->pt_sposA, *spos_b = seeding ? nullptr : c->pt_sposB;
-    uint8_t *sdig_a = seeding ? nullptr : c->pt_sdigA, *sdig_b = seeding ? nullptr : c->pt_sdigB;
     if (d_keys)
         hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_histA);
     else if (c->cfg.canonical)
@@ -1478,20 +1474,20 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     const uint32_t ga = (uint32_t)((ta + 7) / 8 * 8), gb = (uint32_t)((tb + 7) / 8 * 8);
     if (d_keys)
         hipLaunchKernelGGL((k_pt_scatter<uint32_t>), ga, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, c->pt_scanA,
-                           c->pt_keysA, spos_a, sdig_a);
+                           c->pt_keysA, spos_a);
     else if (c->cfg.canonical)
         hipLaunchKernelGGL((k_pt_scatter_words<true>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a,
-                           c->pt_scanA, c->pt_keysA, spos_a, sdig_a);
+                           c->pt_scanA, c->pt_keysA, spos_a);
     else
         hipLaunchKernelGGL((k_pt_scatter_words<false>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a,
-                           c->pt_scanA, c->pt_keysA, spos_a, sdig_a);
+                           c->pt_scanA, c->pt_keysA, spos_a);
     hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_histB);
     hipLaunchKernelGGL(k_pt_colsum, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, cb, c->pt_totals);
     hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 0, c->pt_startB);
     hipLaunchKernelGGL(k_pt_rowscan, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
     hipLaunchKernelGGL((k_pt_scatter<uint16_t>), gb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, c->pt_scanB,
-                       c->pt_keysB, spos_b, sdig_b);
+                       c->pt_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -1504,9 +1500,9 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
                        (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
-        hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, c->pt_sdigB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
+        hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
                            c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_pt_ungather, ga, PU_THREADS, 0, c->stream, c->pt_sposA, c->pt_sdigA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
+        hipLaunchKernelGGL(k_pt_ungather, ga, PU_THREADS, 0, c->stream, c->pt_sposA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
                            c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW, d_flags ? (uint32_t *)nullptr : c->d_wflags);
         HIPCHK(c, hipGetLastError());
     }
@@ -1691,7 +1687,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
     hipFree(c->pt_table); hipFree(c->pt_keys); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flags); hipFree(c->pt_flagsA);
     hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
-    hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB); hipFree(c->pt_sdigA); hipFree(c->pt_sdigB);
+    hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
