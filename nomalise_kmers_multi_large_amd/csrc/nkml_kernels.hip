@@ -1040,7 +1040,8 @@ struct nkml_ctx {
     uint32_t *pt_keys, *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
     uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
-    uint16_t *pt_keysB, *pt_sposA, *pt_sposB; // spos: what the forward passes leave for the reverse passes
+    uint16_t *pt_keysB;
+    uint32_t *pt_sposA, *pt_sposB; // sorted positions, 12 bits each: what the forward passes leave for the reverse passes
     uint8_t *pt_flags, *pt_flagsA, *pt_flagsB;
     uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
     uint64_t pt_timed_keys;
@@ -1142,8 +1143,8 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_flagsA, na));
         HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
         HIPCHK(c, hipMalloc(&c->pt_flagsB, npos));
-        HIPCHK(c, hipMalloc(&c->pt_sposA, c->pt_tiles_a * PT_TILE * sizeof(uint16_t)));
-        HIPCHK(c, hipMalloc(&c->pt_sposB, na * sizeof(uint16_t)));
+        HIPCHK(c, hipMalloc(&c->pt_sposA, c->pt_tiles_a * PT_TILE / 8 * 3 * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_sposB, na / 8 * 3 * sizeof(uint32_t)));
         // histograms and their scans: one row of 256 per tile plus the all-zero row after the last tile
         HIPCHK(c, hipMalloc(&c->pt_histA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_scanA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
@@ -1459,7 +1460,7 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     const uint64_t n_words = n / 16;
     const int k = c->cfg.ksize;
-    uint16_t *spos_a = seeding ? nullptr : c->pt_sposA, *spos_b = seeding ? nullptr : c->pt_sposB;
+    uint32_t *spos_a = seeding ? nullptr : c->pt_sposA, *spos_b = seeding ? nullptr : c->pt_sposB;
     if (d_keys)
         hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_histA);
     else if (c->cfg.canonical)
