@@ -128,7 +128,9 @@ int nkml_host_staging(nkml_ctx *ctx, uint8_t **seq, uint64_t **offsets);
 int nkml_wait_staged(nkml_ctx *ctx);
 
 /* Device-buffer path: the same batch already resident in HBM; d_high/d_total are device arrays of n_reads.
- * Asynchronous on the context's stream. */
+ * Runs on the context's stream; the call waits for the device once per batch (for the number of occurrences to
+ * rank on the atomic path, for the bad-base tally on the partitioned path) and returns NKML_E_BADBASE if the batch
+ * held a byte outside ACGTN. */
 int nkml_process_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads,
                         uint64_t n_bases, int32_t *d_high, int32_t *d_total);
 
