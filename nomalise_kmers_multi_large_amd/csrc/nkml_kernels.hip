@@ -1037,12 +1037,12 @@ struct nkml_ctx {
     // partitioned counting (k <= 15, depth <= 127): one byte per k-mer and the buffers of the two radix passes
     bool partitioned;
     uint8_t *pt_table;
-    uint32_t *pt_keys, *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
+    uint32_t *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
     uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
     uint16_t *pt_keysB;
     uint32_t *pt_sposA, *pt_sposB; // sorted positions, 12 bits each: what the forward passes leave for the reverse passes
-    uint8_t *pt_flags, *pt_flagsA, *pt_flagsB;
+    uint8_t *pt_flagsA, *pt_flagsB;
     uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
     uint64_t pt_timed_keys;
     bool pt_timing_pending;
@@ -1137,8 +1137,6 @@ int alloc_table(nkml_ctx *c)
         c->pt_tiles_a = (npos + PT_TILE - 1) / PT_TILE;
         c->pt_tiles_b = c->pt_tiles_a + 256 + 1;
         const uint64_t na = (c->pt_tiles_b + 1) * PT_TILE;
-        HIPCHK(c, hipMalloc(&c->pt_keys, npos * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->pt_flags, npos));
         HIPCHK(c, hipMalloc(&c->pt_keysA, na * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_flagsA, na));
         HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
@@ -1657,12 +1655,12 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     CREATE_HIP(hipMalloc(&c->d_wflags, (c->max_words + 4) * sizeof(uint32_t)));
     CREATE_HIP(hipMalloc(&c->d_high, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
     CREATE_HIP(hipMalloc(&c->d_total, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
-    const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
-    CREATE_HIP(hipMalloc(&c->d_list_sat, per_chunk * c->key_bytes));
-    CREATE_HIP(hipMalloc(&c->d_list_cross, per_chunk * c->key_bytes));
-    CREATE_HIP(hipMalloc(&c->d_occ, npos * sizeof(unsigned long long)));
-    CREATE_HIP(hipMalloc(&c->d_occ_sorted, npos * sizeof(unsigned long long)));
-    {
+    if (!c->partitioned) { // lists and sort buffers of the atomic path's order fix-up
+        const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
+        CREATE_HIP(hipMalloc(&c->d_list_sat, per_chunk * c->key_bytes));
+        CREATE_HIP(hipMalloc(&c->d_list_cross, per_chunk * c->key_bytes));
+        CREATE_HIP(hipMalloc(&c->d_occ, npos * sizeof(unsigned long long)));
+        CREATE_HIP(hipMalloc(&c->d_occ_sorted, npos * sizeof(unsigned long long)));
         size_t tmp = 0;
         CREATE_HIP(rocprim::radix_sort_keys(nullptr, tmp, c->d_occ, c->d_occ_sorted, (size_t)npos, 0u, 64u, c->stream));
         c->sort_tmp_bytes = tmp ? tmp : 256;
@@ -1686,7 +1684,7 @@ void nkml_destroy(nkml_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
-    hipFree(c->pt_table); hipFree(c->pt_keys); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flags); hipFree(c->pt_flagsA);
+    hipFree(c->pt_table); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flagsA);
     hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
     hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
