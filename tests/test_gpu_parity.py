@@ -475,3 +475,28 @@ def test_two_ranks_share_one_gpu_equal_single_table(nk):
                 np.testing.assert_array_equal(got[step][r][1], t[:nr].cpu().numpy())
                 crossed += int(h[:nr].sum())
         assert crossed > 0
+
+
+@pytest.mark.parametrize("k", [14, 15])
+def test_partitioned_equals_atomic_on_odd_batch_sizes(nk, k):
+    """Batches of 1, 13, 14, 27, 28, 55 and 1000 pairs in a row (tile and word boundaries of the partition passes fall
+    inside and between them): the partitioned path gives the per-read counters of the atomic path."""
+    import torch
+    from nomalise_kmers_multi_large_amd import synth
+    sizes = [1, 13, 14, 27, 28, 55, 1000, 1, 2731]
+    c1, c2 = next(synth.pair_blocks(sum(sizes), seed=21, transcripts=3, block=sum(sizes)))
+    got = {}
+    for on in (False, True):
+        with partitioned_mode(on), nk.KmerNormaliser(k, 7, 0.9, max_batch_reads=8192, max_batch_bases=8192 * 150) as g:
+            out, at = [], 0
+            for n in sizes:
+                seq, off = synth.interleave(c1[at:at + n], c2[at:at + n])
+                at += n
+                out.append(g.process_batch(seq, off))
+            got[on] = (out, g.unique_kmers, g.stats()["partitioned"])
+    assert got[True][2] == 1 and got[False][2] == 0
+    assert got[True][1] == got[False][1]
+    for (ha, ta), (hp, tp) in zip(got[False][0], got[True][0]):
+        np.testing.assert_array_equal(hp, ha)
+        np.testing.assert_array_equal(tp, ta)
+    assert sum(int(h.sum()) for h, _ in got[True][0]) > 0
