@@ -178,6 +178,26 @@ int nkml_route_reads_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t 
 int nkml_unroute_flags_device(nkml_ctx *ctx, const uint8_t *d_recv_flags, const uint32_t *d_send_src, uint64_t n_sent,
                               uint8_t *d_flags, uint64_t n_keys);
 
+/* The other way to spread one table over a few devices: every device sees every read of a step and counts only
+ * the k-mers of its own table shard, so nothing per k-mer crosses a link - only the 2-bit packed reads (one all-gather)
+ * and the per-read partial counters (one sum).  Worth it while the step's reads, times the number of devices, still
+ * fit one context (positions stay below 2^32) - two to four devices.  New like the exchange above (ref:2421).
+ *   set_shard      : from now on the context counts only k-mers with shard_of(key, n_shards) == shard (partitioned
+ *                    counting path only, else NKML_E_STATE); (0, 1) switches the filter off.  The per-read high and
+ *                    total then are this shard's share; summed over all shards they are the single-table numbers.
+ *   shard_of       : the shard of a k-mer code below 2^32 (host function, same rule as the kernels).
+ *   pack           : sequence bytes -> 2-bit packed words, 16 bases per word, first base in the top bits (the order
+ *                    of encode_kmer_plain, ref:1118-1126), the tail of the last word filled with A.  Asynchronous; a
+ *                    byte outside ACGTN is reported by the context's next call that waits.
+ *   process_packed : nkml_process_device for a batch that is already packed.  d_offsets may leave gaps between
+ *                    reads' words as long as it is non-decreasing: list a gap as a read of its own (if it holds only
+ *                    A it has no countable k-mer).  Waits like nkml_process_device. */
+int nkml_set_shard(nkml_ctx *ctx, uint32_t shard, uint32_t n_shards);
+int nkml_shard_of(uint64_t key, uint32_t n_shards);
+int nkml_pack_device(nkml_ctx *ctx, const uint8_t *d_seq, uint64_t n_bases, uint32_t *d_words);
+int nkml_process_packed_device(nkml_ctx *ctx, const uint32_t *d_words, const uint64_t *d_offsets, uint32_t n_reads,
+                               uint64_t n_bases, int32_t *d_high, int32_t *d_total);
+
 #define NKML_FLAG_NONE 0u /* no k-mer at this position */
 #define NKML_FLAG_HIGH 1u /* occurrence whose stream-order count is >= depth */
 #define NKML_FLAG_LOW 2u  /* counted, below depth */

@@ -11,6 +11,9 @@ _LIB = None
 NKML_OK = 0
 NKML_E_ARG, NKML_E_HIP, NKML_E_NOMEM, NKML_E_BADBASE, NKML_E_STATE, NKML_E_NODEVICE = -1, -2, -3, -4, -5, -6
 NKML_F_PROFILE = 1
+NKML_F_EXACT_COUNTS = 2
+NKML_F_COUNT_ATOMIC = 4
+NKML_F_COUNT_PARTITIONED = 8
 FLAG_NONE, FLAG_HIGH, FLAG_LOW = 0, 1, 2
 
 # every symbol include/nkml_hip.h declares
@@ -19,7 +22,7 @@ EXPORTS = [
     "nkml_set_stream", "nkml_synchronize", "nkml_get_stats", "nkml_submit", "nkml_collect", "nkml_process_device",
     "nkml_seed", "nkml_keep_pair", "nkml_keep_single", "nkml_decide_device", "nkml_key_bytes", "nkml_kmerise_device",
     "nkml_count_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_reads_device",
-    "nkml_unroute_flags_device",
+    "nkml_unroute_flags_device", "nkml_set_shard", "nkml_shard_of", "nkml_pack_device", "nkml_process_packed_device",
 ]
 
 
@@ -96,5 +99,9 @@ def load_library():
     lib.nkml_route_keys_device.argtypes = [vp, vp, u64, u32, vp, vp, ctypes.POINTER(u64)]
     lib.nkml_route_reads_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, ctypes.POINTER(u64)]
     lib.nkml_unroute_flags_device.argtypes = [vp, vp, vp, u64, vp, u64]
+    lib.nkml_set_shard.argtypes = [vp, u32, u32]
+    lib.nkml_shard_of.argtypes = [u64, u32]
+    lib.nkml_pack_device.argtypes = [vp, vp, u64, vp]
+    lib.nkml_process_packed_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
     _LIB = lib
     return lib

@@ -1056,6 +1056,7 @@ struct nkml_ctx {
     uint8_t *d_seq;
     uint64_t *d_offsets;
     uint32_t *d_packed, *d_startbits;
+    uint32_t n_shards = 1, shard = 0; // replicated-reads mode: this context counts only the k-mers of its shard
     uint32_t *d_wflags;     // per packed word: HIGH bits (low half) and LOW bits (high half) of its 16 windows
     int32_t *d_high, *d_total;
 
@@ -1462,9 +1463,9 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
     if (d_keys)
         hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, shift_a, ta, c->pt_histA);
     else if (c->cfg.canonical)
-        hipLaunchKernelGGL((k_pt_hist_words<true>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a, c->pt_histA);
+        hipLaunchKernelGGL((k_pt_hist_words<true>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a, c->n_shards, c->shard, c->pt_histA);
     else
-        hipLaunchKernelGGL((k_pt_hist_words<false>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a, c->pt_histA);
+        hipLaunchKernelGGL((k_pt_hist_words<false>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a, c->n_shards, c->shard, c->pt_histA);
     hipLaunchKernelGGL(k_pt_colsum, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, ca, c->pt_totals);
     hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 1, c->pt_pad);
@@ -1476,10 +1477,10 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
                            c->pt_keysA, spos_a);
     else if (c->cfg.canonical)
         hipLaunchKernelGGL((k_pt_scatter_words<true>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a,
-                           c->pt_scanA, c->pt_keysA, spos_a);
+                           c->n_shards, c->shard, c->pt_scanA, c->pt_keysA, spos_a);
     else
         hipLaunchKernelGGL((k_pt_scatter_words<false>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, shift_a,
-                           c->pt_scanA, c->pt_keysA, spos_a);
+                           c->n_shards, c->shard, c->pt_scanA, c->pt_keysA, spos_a);
     hipLaunchKernelGGL((k_pt_hist<uint32_t>), (uint32_t)tb, 256, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, tb, c->pt_histB);
     hipLaunchKernelGGL(k_pt_colsum, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, cb, c->pt_totals);
@@ -1814,6 +1815,59 @@ int nkml_process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_off
                         int32_t *d_high, int32_t *d_total)
 {
     return process_device(c, d_seq, d_offsets, n_reads, n_bases, d_high, d_total, false);
+}
+
+int nkml_set_shard(nkml_ctx *c, uint32_t shard, uint32_t n_shards)
+{
+    if (!c) return NKML_E_ARG;
+    if (n_shards == 0 || shard >= n_shards || n_shards > 65535) return fail(c, NKML_E_ARG, "shard %u of %u", shard, n_shards);
+    if (n_shards > 1 && !c->partitioned) return fail(c, NKML_E_STATE, "table shards need the partitioned counting path");
+    c->n_shards = n_shards;
+    c->shard = shard;
+    return NKML_OK;
+}
+
+int nkml_shard_of(uint64_t key, uint32_t n_shards)
+{
+    if (n_shards == 0 || n_shards > 65535 || key >> 32) return NKML_E_ARG;
+    return (int)pt_shard_of((uint32_t)key, n_shards);
+}
+
+int nkml_pack_device(nkml_ctx *c, const uint8_t *d_seq, uint64_t n_bases, uint32_t *d_words)
+{
+    if (!c || !d_seq || !d_words) return NKML_E_ARG;
+    if (n_bases == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t n_words = (n_bases + 15) / 16;
+    hipLaunchKernelGGL(k_pack, blocks_for(n_words), 256, 0, c->stream, d_seq, n_bases, d_words, n_words, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int nkml_process_packed_device(nkml_ctx *c, const uint32_t *d_words, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
+                               int32_t *d_high, int32_t *d_total)
+{
+    if (!c || !d_words || !d_offsets || !d_high || !d_total) return NKML_E_ARG;
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    if (n_reads == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t n_words = (n_bases + 15) / 16;
+    HIPCHK(c, hipMemsetAsync(c->d_startbits, 0, (n_words + 4) * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_packed + n_words, 0, 4 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_packed, d_words, n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_mark_starts, blocks_for((uint64_t)n_reads + 1), 256, 0, c->stream, d_offsets, n_reads, c->d_startbits);
+    HIPCHK(c, hipGetLastError());
+    if (c->partitioned) {
+        if ((rc = run_count_partitioned(c, nullptr, n_words * 16, n_bases, nullptr, false)) != NKML_OK) return rc;
+        if ((rc = run_reduce_words(c, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
+        if ((rc = fetch_counters(c)) != NKML_OK) return rc; // the one wait of the batch
+        if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
+        return check_bad_bases(c);
+    }
+    if ((rc = run_fused(c, n_bases, false)) != NKML_OK) return rc;
+    if ((rc = check_bad_bases(c)) != NKML_OK) return rc;
+    return run_reduce_words(c, d_offsets, n_reads, d_high, d_total);
 }
 
 static int stage_host_batch(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads, uint64_t *n_bases_out)

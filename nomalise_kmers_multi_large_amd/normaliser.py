@@ -15,12 +15,12 @@ from . import binding as B
 
 class KmerNormaliser:
     def __init__(self, ksize=15, depth=100, coverage=0.9, canonical=False, memory_gb=0, device=0,
-                 max_batch_reads=1 << 20, max_batch_bases=1 << 28, chunk_bases=0, profile=False):
+                 max_batch_reads=1 << 20, max_batch_bases=1 << 28, chunk_bases=0, profile=False, flags=0):
         self.lib = B.load_library()
         self.ksize, self.depth, self.canonical = int(ksize), int(depth), bool(canonical)
         self.coverage = np.float32(coverage)
         cfg = B.Config(self.ksize, self.depth, int(self.canonical), int(device), int(memory_gb), int(max_batch_reads),
-                       int(max_batch_bases), int(chunk_bases), B.NKML_F_PROFILE if profile else 0)
+                       int(max_batch_bases), int(chunk_bases), (B.NKML_F_PROFILE if profile else 0) | int(flags))
         self.max_batch_reads, self.max_batch_bases = int(max_batch_reads), int(max_batch_bases)
         h = ctypes.c_void_p()
         rc = self.lib.nkml_create(ctypes.byref(cfg), ctypes.byref(h))
@@ -168,6 +168,16 @@ class KmerNormaliser:
     # -- device-buffer path (pointers are plain integers, e.g. torch.Tensor.data_ptr()) -----------------
     def process_device(self, d_seq, d_offsets, n_reads, n_bases, d_high, d_total):
         self._chk(self.lib.nkml_process_device(self.h, d_seq, d_offsets, n_reads, n_bases, d_high, d_total))
+
+    def set_shard(self, shard, n_shards):
+        """Count only the k-mers of table shard `shard` of `n_shards` from now on (replicated-reads multi-GPU mode)."""
+        self._chk(self.lib.nkml_set_shard(self.h, shard, n_shards))
+
+    def pack_device(self, d_seq, n_bases, d_words):
+        self._chk(self.lib.nkml_pack_device(self.h, d_seq, n_bases, d_words))
+
+    def process_packed_device(self, d_words, d_offsets, n_reads, n_bases, d_high, d_total):
+        self._chk(self.lib.nkml_process_packed_device(self.h, d_words, d_offsets, n_reads, n_bases, d_high, d_total))
 
     def decide_device(self, d_high, d_total, n_units, paired, d_keep):
         self._chk(self.lib.nkml_decide_device(self.h, d_high, d_total, n_units, int(paired), self.coverage, d_keep))

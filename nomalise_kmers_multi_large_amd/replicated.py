@@ -1,0 +1,177 @@
+"""Replicated-reads normaliser for two to four GPUs of one node: the table is sharded by k-mer as in
+`sharded.py`, but instead of sending every k-mer to its owner, every GPU gets every read of the step (2-bit packed,
+one all-gather) and counts only the k-mers of its own shard.  Per-read partial counters are then summed over the
+ranks.  Nothing per k-mer crosses a link: 0.25 byte per base goes out once, against 5 bytes per k-mer of the
+all-to-all exchange, which matters most on two GPUs, where all of it shares one xGMI link.  The price is that the
+first partition pass reads world_size times the positions, so the all-to-all path wins again from about eight GPUs on,
+and positions of one step must stay below 2^32 (world_size x bases per rank).
+
+Results are those of one table reading the global stream (per step: rank 0's reads, then rank 1's, ...), like
+`ShardedNormaliser`; the reference has no counterpart (its threads keep private tables, normalise_kmers_multi_large.c:2421).
+
+Layout of one step on every rank: rank r's packed words sit in region r of `region` words (the largest word count of the
+step, the same on all ranks); what is left of a region after its reads is zero = poly-A, which has no countable k-mer
+(code 0 is skipped like in the reference's table, :929-1053 store_kmer callers), and is listed as filler reads so that
+the read offsets stay one non-decreasing array.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import binding as B
+
+GAP_READS = 1024     # a region's unused tail is cut into at most this many filler reads ...
+GAP_BASES = 4096     # ... of at least this many bases (one lane walks one read in the per-read reduction)
+POSITION_LIMIT = (1 << 32) - (4 << 20)
+
+
+def fits(ksize, depth, world, max_bases):
+    """Whether a step of `world` ranks x max_bases fits the replicated-reads mode."""
+    region = (max_bases + 15) // 16 * 16
+    return 14 <= ksize <= 15 and depth <= 127 and world * region < POSITION_LIMIT
+
+
+def step_layout(n_reads, n_bases):
+    """Host-side plan of one step from every rank's (reads, bases): region size in words, per rank the number of
+    filler reads and the index of its first read in the global read list, and the total number of reads."""
+    region = max((int(b) + 15) // 16 for b in n_bases)
+    fillers, first, at = [], [], 0
+    for r, b in zip(n_reads, n_bases):
+        gap = region * 16 - int(b)
+        e = min(GAP_READS, max(1, -(-gap // GAP_BASES)))
+        fillers.append(e)
+        first.append(at)
+        at += int(r) + e
+    return region, fillers, first, at
+
+
+def global_offsets(local_offsets, n_reads, n_bases, region, fillers):
+    """The step's read offsets (int64 tensor on the device of the inputs) from each rank's own offsets
+    (local_offsets[r][: n_reads[r] + 1], any integer dtype): rank r's reads moved to region r, then its filler reads."""
+    parts = []
+    dev = local_offsets[0].device
+    for r, (off, nr, nb, e) in enumerate(zip(local_offsets, n_reads, n_bases, fillers)):
+        base = r * region * 16
+        parts.append(off[: nr + 1].to(torch.int64) + base)
+        if e > 1:
+            gap = region * 16 - nb
+            j = torch.arange(1, e, dtype=torch.int64, device=dev)
+            parts.append(base + nb + (j * gap) // e)
+    parts.append(torch.tensor([len(local_offsets) * region * 16], dtype=torch.int64, device=dev))
+    return torch.cat(parts)
+
+
+class HipReplicaEngine:
+    """The HIP library on one GPU for the replicated-reads mode: packs this rank's reads, counts a whole step against
+    this rank's table shard."""
+
+    def __init__(self, ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=False):
+        from .normaliser import KmerNormaliser
+        if not fits(ksize, depth, world, max_bases):
+            raise ValueError("replicated-reads mode needs k = 14 or 15, depth <= 127 and world x bases per step below 2^32")
+        self.dev = torch.device("cuda", device)
+        self.max_region = (max_bases + 15) // 16
+        self.max_reads = max_reads
+        all_reads = world * (max_reads + GAP_READS)
+        self.nk = KmerNormaliser(ksize, depth, coverage, canonical, device=device, max_batch_reads=all_reads,
+                                 max_batch_bases=world * self.max_region * 16, profile=profile, flags=B.NKML_F_COUNT_PARTITIONED)
+        self.nk.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.nk.set_shard(rank, world)
+        self.words = torch.zeros(self.max_region, dtype=torch.int32, device=self.dev)
+        self.words_all = torch.zeros(world * self.max_region, dtype=torch.int32, device=self.dev)
+        self.counters = torch.zeros(2 * all_reads, dtype=torch.int32, device=self.dev)
+
+    def pack(self, seq, n_bases, region):
+        """This rank's reads as `region` packed words (zero beyond the reads)."""
+        nw = (n_bases + 15) // 16
+        if region > self.max_region or nw > region:
+            raise RuntimeError("step of %d words per rank, sized for %d" % (region, self.max_region))
+        self.nk.pack_device(seq.data_ptr(), n_bases, self.words.data_ptr())
+        if region > nw:
+            self.words[nw:region].zero_()
+        return self.words[:region]
+
+    def gather_buffer(self, n_words):
+        return self.words_all[:n_words]
+
+    def process_packed(self, words_all, offsets, n_reads, n_bases):
+        """Returns a [2, n_reads] view (high, total): this shard's share of every read of the step."""
+        out = self.counters[: 2 * n_reads].view(2, n_reads)
+        self.nk.process_packed_device(words_all.data_ptr(), offsets.data_ptr(), n_reads, n_bases, out[0].data_ptr(), out[1].data_ptr())
+        return out
+
+    def decide(self, high, total, n_units, paired, keep):
+        self.nk.decide_device(high.data_ptr(), total.data_ptr(), n_units, paired, keep.data_ptr())
+
+    def synchronize(self):
+        self.nk.synchronize()
+
+    def reset(self):
+        self.nk.reset()
+
+    def stats(self):
+        return self.nk.stats()
+
+
+class ReplicatedReadsNormaliser:
+    """Same face as ShardedNormaliser: one step = every rank's batch, processed as one global batch in rank-major order."""
+
+    def __init__(self, engine, group=None, stage_through_host=False):
+        self.eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        # rehearsal aid only (several ranks on one GPU under gloo): collectives bounce through host memory
+        self.stage_through_host = stage_through_host
+
+    def _gather_equal(self, out, inp):
+        if self.stage_through_host and inp.is_cuda:
+            self.eng.synchronize()
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, inp.cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def _sum(self, t):
+        if self.stage_through_host and t.is_cuda:
+            self.eng.synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
+
+    def process_step(self, seq, offsets, n_reads, n_bases):
+        """seq/offsets: this rank's reads on the device.  Returns (high, total) of this rank's reads and, on rank 0, the
+        list of [2, n_reads_r] counters of every rank's reads."""
+        eng, W = self.eng, self.world
+        cdev = "cpu" if self.stage_through_host or not seq.is_cuda else seq.device
+        meta = torch.empty(2 * W, dtype=torch.int64, device=cdev)
+        self._gather_equal(meta, torch.tensor([n_reads, n_bases], dtype=torch.int64, device=cdev))
+        meta = meta.tolist()
+        all_reads, all_bases = meta[0::2], meta[1::2]
+        region, fillers, first, total_reads = step_layout(all_reads, all_bases)
+        words_all = eng.gather_buffer(W * region)
+        self._gather_equal(words_all, eng.pack(seq, n_bases, region))
+        # read offsets travel as 32-bit numbers local to the rank's region
+        slot = max(all_reads) + 1
+        mine = torch.zeros(slot, dtype=torch.int32, device=seq.device)
+        mine[: n_reads + 1] = offsets[: n_reads + 1]
+        off_all = torch.empty(W * slot, dtype=torch.int32, device=seq.device)
+        self._gather_equal(off_all, mine)
+        goff = global_offsets([off_all[r * slot:(r + 1) * slot] for r in range(W)], all_reads, all_bases, region, fillers)
+        counters = eng.process_packed(words_all, goff, total_reads, W * region * 16)
+        self._sum(counters)
+        per_rank = [counters[:, first[r]: first[r] + all_reads[r]] for r in range(W)]
+        own = per_rank[self.rank]
+        return own[0], own[1], (per_rank if self.rank == 0 else None)
+
+    def synchronize(self):
+        self.eng.synchronize()
+
+    def reset(self):
+        self.eng.reset()
+
+    def stats(self):
+        return self.eng.stats()

@@ -500,3 +500,170 @@ def test_partitioned_equals_atomic_on_odd_batch_sizes(nk, k):
         np.testing.assert_array_equal(hp, ha)
         np.testing.assert_array_equal(tp, ta)
     assert sum(int(h.sum()) for h, _ in got[True][0]) > 0
+
+
+def test_table_shards_add_up_to_the_single_table(nk):
+    """Three contexts on one GPU, each counting only its table shard of the same batches: per-read high and total
+    summed over the shards, and the shards' distinct k-mers, equal the unsharded context's."""
+    from nomalise_kmers_multi_large_amd import binding, synth
+    n_shards, bp = 3, 20000
+    mk = lambda: nk.KmerNormaliser(15, 20, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150, flags=binding.NKML_F_COUNT_PARTITIONED)
+    whole, parts = mk(), [mk() for _ in range(n_shards)]
+    try:
+        for s, g in enumerate(parts):
+            g.set_shard(s, n_shards)
+        seen = 0
+        for c1, c2 in synth.pair_blocks(3 * bp, seed=9, transcripts=25, block=bp):
+            seq, off = synth.interleave(c1, c2)
+            h, t = whole.process_batch(seq, off)
+            got = [g.process_batch(seq, off) for g in parts]
+            np.testing.assert_array_equal(sum(x[0] for x in got), h)
+            np.testing.assert_array_equal(sum(x[1] for x in got), t)
+            assert all(x[1].sum() > 0.2 * t.sum() for x in got)   # every shard carries its share
+            seen += int(h.sum())
+        assert seen > 0
+        assert sum(g.unique_kmers for g in parts) == whole.unique_kmers
+        with pytest.raises(binding.NkmlError):
+            parts[0].set_shard(3, 3)
+    finally:
+        for g in [whole] + parts:
+            g.close()
+    with nk.KmerNormaliser(25, 20, 0.9, True, max_batch_reads=64, max_batch_bases=6400) as g:   # hashed table: atomic path
+        with pytest.raises(binding.NkmlError):
+            g.set_shard(0, 2)
+        g.set_shard(0, 1)
+
+
+@pytest.mark.parametrize("k,canonical", [(15, False), (14, True), (25, True), (11, False)])
+def test_packed_input_equals_sequence_input(nk, k, canonical):
+    """nkml_pack_device + nkml_process_packed_device against nkml_process_device on the same batches (reads with N,
+    lengths that are no multiple of 16): the same counters, and the packed words are the 2-bit codes, first base on top."""
+    import torch
+    rng = np.random.default_rng(k)
+    a, b = (nk.KmerNormaliser(k, 3, 0.9, canonical, max_batch_reads=4096, max_batch_bases=1 << 20) for _ in range(2))
+    try:
+        for step in range(3):
+            reads = random_reads(rng, 900 + step, k, 211, n_rate=0.01)
+            seq, off = nk.KmerNormaliser._concat(reads)
+            nr, nb = len(reads), len(seq)
+            d_seq, d_off = torch.from_numpy(seq.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+            words = torch.full(((nb + 15) // 16,), -1, dtype=torch.int32, device="cuda")
+            out = torch.zeros((4, nr), dtype=torch.int32, device="cuda")
+            a.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, nb, out[0].data_ptr(), out[1].data_ptr())
+            b.pack_device(d_seq.data_ptr(), nb, words.data_ptr())
+            b.process_packed_device(words.data_ptr(), d_off.data_ptr(), nr, nb, out[2].data_ptr(), out[3].data_ptr())
+            a.synchronize()
+            b.synchronize()
+            o = out.cpu().numpy()
+            np.testing.assert_array_equal(o[2], o[0])
+            np.testing.assert_array_equal(o[3], o[1])
+            assert o[1].sum() > 0
+            code = np.zeros(256, dtype=np.uint32)
+            code[list(b"ACGT")] = [0, 1, 2, 3]
+            padded = np.zeros(len(words) * 16, dtype=np.uint32)
+            padded[:nb] = code[seq]
+            want = (padded.reshape(-1, 16) << np.arange(30, -2, -2, dtype=np.uint32)).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+            np.testing.assert_array_equal(words.cpu().numpy().view(np.uint32), want)
+        assert a.unique_kmers == b.unique_kmers
+    finally:
+        a.close()
+        b.close()
+
+
+def _replica_worker(rank, world, port, steps, bp, q):
+    import torch
+    import torch.distributed as dist
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.replicated import HipReplicaEngine, ReplicatedReadsNormaliser
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = HipReplicaEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, world=world, rank=rank)
+        rn = ReplicatedReadsNormaliser(eng, stage_through_host=True)
+        # rank 1 brings a third less per step, so its region ends in filler
+        mine = bp if rank == 0 else bp * 2 // 3
+        blocks = list(synth.pair_blocks(steps * mine, seed=11 + rank, transcripts=30, block=mine))
+        out = []
+        for c1, c2 in blocks:
+            seq, off = synth.interleave(c1, c2)
+            high, total, gathered = rn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq))
+            rn.synchronize()
+            if rank == 0:
+                out.append([g.cpu().numpy().copy() for g in gathered])
+        uniq = torch.tensor([rn.stats()["unique_kmers"]], dtype=torch.int64)
+        dist.all_reduce(uniq)
+        if rank == 0:
+            q.put((out, int(uniq.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_replica_ranks_share_one_gpu_equal_single_table(nk):
+    """The replicated-reads mode with the product engine: two ranks (each its own context and table shard on this GPU),
+    collectives over gloo through host memory.  The counters on rank 0 equal those of one table reading the global stream."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from nomalise_kmers_multi_large_amd import synth
+    world, steps, bp = 2, 3, 15000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, steps, bp, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, uniq = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sizes = [bp, bp * 2 // 3]
+    data = [list(synth.pair_blocks(steps * sizes[r], seed=11 + r, transcripts=30, block=sizes[r])) for r in range(world)]
+    with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
+        crossed = 0
+        for step in range(steps):
+            for r in range(world):
+                h, t = g.process_batch(*synth.interleave(*data[r][step]))
+                np.testing.assert_array_equal(got[step][r][0], h)
+                np.testing.assert_array_equal(got[step][r][1], t)
+                crossed += int(h.sum())
+        assert crossed > 0 and uniq == g.unique_kmers
+
+
+def test_replicated_normaliser_over_rccl_world_of_one(nk):
+    """ReplicatedReadsNormaliser end to end over the real RCCL backend (world size 1 on this box): all-gather and
+    sum are the real collectives; counters equal the plain single-table path."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.replicated import HipReplicaEngine, ReplicatedReadsNormaliser
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bp = 20000
+        eng = HipReplicaEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, world=1, rank=0)
+        rn = ReplicatedReadsNormaliser(eng)
+        with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
+            seen = 0
+            for c1, c2 in synth.pair_blocks(3 * bp, seed=5, transcripts=40, block=bp):
+                seq, off = synth.interleave(c1, c2)
+                nr, nb = len(off) - 1, len(seq)
+                high, total, gathered = rn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), nr, nb)
+                rn.synchronize()
+                h, t = g.process_batch(seq, off)
+                np.testing.assert_array_equal(high.cpu().numpy(), h)
+                np.testing.assert_array_equal(total.cpu().numpy(), t)
+                np.testing.assert_array_equal(gathered[0][1].cpu().numpy(), t)
+                seen += int(h.sum())
+            assert seen > 0 and eng.stats()["unique_kmers"] == g.unique_kmers
+    finally:
+        dist.destroy_process_group()
