@@ -191,9 +191,9 @@ def main():
             eng.synchronize()
             torch.cuda.synchronize()
     else:
-        from nomalise_kmers_multi_large_amd.sharded import HipShardEngine, ShardedNormaliser
-        engine = HipShardEngine(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN, profile=True)
-        eng = ShardedNormaliser(engine, stage_through_host=rehearse)
+        from nomalise_kmers_multi_large_amd.replicated import make_multi_gpu_normaliser
+        eng, engine, multi_mode = make_multi_gpu_normaliser(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
+                                                            profile=True, stage_through_host=rehearse)
         d_keep_all = torch.zeros((len(dev_steps), world, pps), dtype=torch.uint8, device=dev) if rank == 0 else None
 
         def step(i):
@@ -291,8 +291,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
             "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d depth=%d coverage=%g, %s" % (
-                n_pairs, k, depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (RCCL all-to-all)" % world),
-                "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d" % world,
+                n_pairs, k, depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
+                    world, "packed reads all-gathered, every GPU counts its shard" if multi_mode == "replicated" else "RCCL all-to-all of k-mers")),
+                "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d (%s)" % (world, multi_mode),
                 "distinct_steps_of_data": data_steps},
             "unique_kmers": unique,
             "unique_kmers_per_s": unique / elapsed,

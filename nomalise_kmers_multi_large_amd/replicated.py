@@ -175,3 +175,23 @@ class ReplicatedReadsNormaliser:
 
     def stats(self):
         return self.eng.stats()
+
+
+def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False,
+                              stage_through_host=False, mode=None, group=None):
+    """The multi-GPU normaliser that suits the job: replicated reads on two or three GPUs when a step fits one context
+    (one xGMI link would carry the whole key exchange of two GPUs; measured per-rank compute of a 2 M-pair step at k=15:
+    10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs, plus one all-gather of packed reads and one sum of counters), the key
+    exchange of `sharded.py` otherwise.  `mode` or the environment variable NKML_MULTI_GPU ("replicated" / "exchange")
+    overrides the choice.  Returns (normaliser, engine, mode)."""
+    import os
+    from .sharded import HipShardEngine, ShardedNormaliser
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mode = mode or os.environ.get("NKML_MULTI_GPU") or ("replicated" if world <= 3 and fits(ksize, depth, world, max_bases) else "exchange")
+    if mode == "replicated":
+        engine = HipReplicaEngine(ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=profile)
+        return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host), engine, mode
+    if mode != "exchange":
+        raise ValueError("NKML_MULTI_GPU must be 'replicated' or 'exchange', not %r" % mode)
+    engine = HipShardEngine(ksize, depth, coverage, canonical, device, max_reads=max_reads, max_bases=max_bases, profile=profile)
+    return ShardedNormaliser(engine, group=group, stage_through_host=stage_through_host), engine, mode
