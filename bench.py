@@ -181,7 +181,7 @@ def main():
         d_keep_all = torch.zeros((len(dev_steps), pps), dtype=torch.uint8, device=dev)  # one row of decisions per step
         d_keep = d_keep_all[0]
 
-        def step(i):
+        def step(i, last=True):
             i %= len(dev_steps)
             s, o, nr, nb = dev_steps[i]
             eng.process_device(s.data_ptr(), o.data_ptr(), nr, nb, d_high.data_ptr(), d_total.data_ptr())
@@ -196,10 +196,13 @@ def main():
                                                             profile=True, stage_through_host=rehearse)
         d_keep_all = torch.zeros((len(dev_steps), world, pps), dtype=torch.uint8, device=dev) if rank == 0 else None
 
-        def step(i):
+        def step(i, last=True):
             i %= len(dev_steps)
             s, o, nr, nb = dev_steps[i]
-            _, _, gathered = eng.process_step(s, o, nr, nb)
+            if multi_mode == "replicated":  # the next step's reads are exchanged while this step is counted
+                _, _, gathered = eng.process_step(s, o, nr, nb, then=None if last else dev_steps[(i + 1) % len(dev_steps)])
+            else:
+                _, _, gathered = eng.process_step(s, o, nr, nb)
             if rank == 0:  # keep/skip for the whole step, in global stream order (rank-major)
                 for r, buf in enumerate(gathered):
                     engine.decide(buf[0], buf[1], buf.shape[1] // 2, True, d_keep_all[i, r])
@@ -214,7 +217,7 @@ def main():
 
     # warmup: the first steps of the stream, then forget the counts so the timed region starts from an empty table
     for i in range(args.warmup):
-        step(i)
+        step(i, i + 1 == args.warmup)
     sync()
     eng.reset()
     sync()
@@ -223,7 +226,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, i + 1 == args.steps)
     sync()
     barrier()
     elapsed = time.perf_counter() - t0

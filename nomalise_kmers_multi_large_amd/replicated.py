@@ -77,22 +77,24 @@ class HipReplicaEngine:
                                  max_batch_bases=world * self.max_region * 16, profile=profile, flags=B.NKML_F_COUNT_PARTITIONED)
         self.nk.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.nk.set_shard(rank, world)
-        self.words = torch.zeros(self.max_region, dtype=torch.int32, device=self.dev)
-        self.words_all = torch.zeros(world * self.max_region, dtype=torch.int32, device=self.dev)
+        # two sets of exchange buffers: the next step's reads arrive while this step's are counted
+        self.words = [torch.zeros(self.max_region, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.words_all = [torch.zeros(world * self.max_region, dtype=torch.int32, device=self.dev) for _ in range(2)]
         self.counters = torch.zeros(2 * all_reads, dtype=torch.int32, device=self.dev)
 
-    def pack(self, seq, n_bases, region):
+    def pack(self, seq, n_bases, region, buffer=0):
         """This rank's reads as `region` packed words (zero beyond the reads)."""
         nw = (n_bases + 15) // 16
         if region > self.max_region or nw > region:
             raise RuntimeError("step of %d words per rank, sized for %d" % (region, self.max_region))
-        self.nk.pack_device(seq.data_ptr(), n_bases, self.words.data_ptr())
+        words = self.words[buffer]
+        self.nk.pack_device(seq.data_ptr(), n_bases, words.data_ptr())
         if region > nw:
-            self.words[nw:region].zero_()
-        return self.words[:region]
+            words[nw:region].zero_()
+        return words[:region]
 
-    def gather_buffer(self, n_words):
-        return self.words_all[:n_words]
+    def gather_buffer(self, n_words, buffer=0):
+        return self.words_all[buffer][:n_words]
 
     def process_packed(self, words_all, offsets, n_reads, n_bases):
         """Returns a [2, n_reads] view (high, total): this shard's share of every read of the step."""
@@ -123,15 +125,18 @@ class ReplicatedReadsNormaliser:
         self.rank = dist.get_rank(group)
         # rehearsal aid only (several ranks on one GPU under gloo): collectives bounce through host memory
         self.stage_through_host = stage_through_host
+        self._buffer = 0      # which of the engine's two sets of exchange buffers the next step uses
+        self._ahead = None    # the exchange started for the step announced by `then`
 
-    def _gather_equal(self, out, inp):
+    def _gather_equal(self, out, inp, async_op=False):
+        """all-gather of equal pieces; with async_op the returned handle's wait() is owed before `out` is used."""
         if self.stage_through_host and inp.is_cuda:
             self.eng.synchronize()
             h = torch.empty(out.shape, dtype=out.dtype)
             dist.all_gather_into_tensor(h, inp.cpu(), group=self.group)
             out.copy_(h)
-        else:
-            dist.all_gather_into_tensor(out, inp, group=self.group)
+            return None
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
     def _sum(self, t):
         if self.stage_through_host and t.is_cuda:
@@ -142,28 +147,50 @@ class ReplicatedReadsNormaliser:
         else:
             dist.all_reduce(t, group=self.group)
 
-    def process_step(self, seq, offsets, n_reads, n_bases):
-        """seq/offsets: this rank's reads on the device.  Returns (high, total) of this rank's reads and, on rank 0, the
-        list of [2, n_reads_r] counters of every rank's reads."""
+    def _start_exchange(self, seq, offsets, n_reads, n_bases):
+        """Everything of a step that does not need the table: sizes, packing, the two all-gathers (left in flight)."""
         eng, W = self.eng, self.world
         cdev = "cpu" if self.stage_through_host or not seq.is_cuda else seq.device
         meta = torch.empty(2 * W, dtype=torch.int64, device=cdev)
         self._gather_equal(meta, torch.tensor([n_reads, n_bases], dtype=torch.int64, device=cdev))
         meta = meta.tolist()
-        all_reads, all_bases = meta[0::2], meta[1::2]
-        region, fillers, first, total_reads = step_layout(all_reads, all_bases)
-        words_all = eng.gather_buffer(W * region)
-        self._gather_equal(words_all, eng.pack(seq, n_bases, region))
+        x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases), "reads": meta[0::2], "bases": meta[1::2]}
+        x["region"], x["fillers"], x["first"], x["total_reads"] = step_layout(x["reads"], x["bases"])
+        self._buffer ^= 1
+        x["words_all"] = eng.gather_buffer(W * x["region"], self._buffer)
+        mine_words = eng.pack(seq, n_bases, x["region"], self._buffer)
         # read offsets travel as 32-bit numbers local to the rank's region
-        slot = max(all_reads) + 1
-        mine = torch.zeros(slot, dtype=torch.int32, device=seq.device)
+        x["slot"] = max(x["reads"]) + 1
+        mine = torch.zeros(x["slot"], dtype=torch.int32, device=seq.device)
         mine[: n_reads + 1] = offsets[: n_reads + 1]
-        off_all = torch.empty(W * slot, dtype=torch.int32, device=seq.device)
-        self._gather_equal(off_all, mine)
-        goff = global_offsets([off_all[r * slot:(r + 1) * slot] for r in range(W)], all_reads, all_bases, region, fillers)
-        counters = eng.process_packed(words_all, goff, total_reads, W * region * 16)
+        x["off_all"] = torch.empty(W * x["slot"], dtype=torch.int32, device=seq.device)
+        x["works"] = [self._gather_equal(x["words_all"], mine_words, async_op=True), self._gather_equal(x["off_all"], mine, async_op=True)]
+        x["alive"] = (mine, mine_words, seq, offsets)   # nothing the collectives read may be freed before they are waited for
+        return x
+
+    def process_step(self, seq, offsets, n_reads, n_bases, then=None):
+        """seq/offsets: this rank's reads on the device.  Returns (high, total) of this rank's reads and, on rank 0, the
+        list of [2, n_reads_r] counters of every rank's reads (views of a buffer the next step overwrites).
+        then = (seq, offsets, n_reads, n_bases) of the step that follows, if the caller has it already: its reads are
+        packed and exchanged while this step is counted.  All ranks must pass `then` in the same steps, and the next
+        call must be for exactly that batch."""
+        eng, W = self.eng, self.world
+        key = (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases)
+        x, self._ahead = self._ahead, None
+        if x is not None and x["key"] != key:
+            raise RuntimeError("process_step was announced another batch by the previous call's `then`")
+        if x is None:
+            x = self._start_exchange(seq, offsets, n_reads, n_bases)
+        for w in x["works"]:
+            if w is not None:
+                w.wait()
+        slot = x["slot"]
+        goff = global_offsets([x["off_all"][r * slot:(r + 1) * slot] for r in range(W)], x["reads"], x["bases"], x["region"], x["fillers"])
+        if then is not None:
+            self._ahead = self._start_exchange(*then)
+        counters = eng.process_packed(x["words_all"], goff, x["total_reads"], W * x["region"] * 16)
         self._sum(counters)
-        per_rank = [counters[:, first[r]: first[r] + all_reads[r]] for r in range(W)]
+        per_rank = [counters[:, x["first"][r]: x["first"][r] + x["reads"][r]] for r in range(W)]
         own = per_rank[self.rank]
         return own[0], own[1], (per_rank if self.rank == 0 else None)
 

@@ -584,10 +584,12 @@ def _replica_worker(rank, world, port, steps, bp, q):
         # rank 1 brings a third less per step, so its region ends in filler
         mine = bp if rank == 0 else bp * 2 // 3
         blocks = list(synth.pair_blocks(steps * mine, seed=11 + rank, transcripts=30, block=mine))
-        out = []
+        out, batches = [], []
         for c1, c2 in blocks:
             seq, off = synth.interleave(c1, c2)
-            high, total, gathered = rn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq))
+            batches.append((torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq)))
+        for i, b in enumerate(batches):   # every step but the last announces the next one
+            high, total, gathered = rn.process_step(*b, then=batches[i + 1] if i + 1 < len(batches) else None)
             rn.synchronize()
             if rank == 0:
                 out.append([g.cpu().numpy().copy() for g in gathered])
@@ -654,11 +656,11 @@ def test_replicated_normaliser_over_rccl_world_of_one(nk):
         rn = ReplicatedReadsNormaliser(eng)
         with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
             seen = 0
-            for c1, c2 in synth.pair_blocks(3 * bp, seed=5, transcripts=40, block=bp):
-                seq, off = synth.interleave(c1, c2)
-                nr, nb = len(off) - 1, len(seq)
-                high, total, gathered = rn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), nr, nb)
-                rn.synchronize()
+            host = [synth.interleave(c1, c2) for c1, c2 in synth.pair_blocks(4 * bp, seed=5, transcripts=40, block=bp)]
+            dev = [(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq)) for seq, off in host]
+            for i, (seq, off) in enumerate(host):
+                # steps 0 and 1 announce their successor (its all-gather overlaps the counting), step 2 does not
+                high, total, gathered = rn.process_step(*dev[i], then=dev[i + 1] if i < 2 else None)
                 h, t = g.process_batch(seq, off)
                 np.testing.assert_array_equal(high.cpu().numpy(), h)
                 np.testing.assert_array_equal(total.cpu().numpy(), t)

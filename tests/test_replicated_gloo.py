@@ -27,13 +27,13 @@ class CheckerReplicaEngine:
         self.k, self.canonical, self.world, self.rank = k, canonical, world, rank
         self.o = Oracle(k, depth, canonical)
 
-    def pack(self, seq, n_bases, region):
+    def pack(self, seq, n_bases, region, buffer=0):
         codes = np.zeros(region * 16, dtype=np.uint32)
         codes[:n_bases] = CODE[seq.numpy()[:n_bases]]
         words = (codes.reshape(region, 16) << SHIFTS).sum(axis=1, dtype=np.uint64).astype(np.uint32)
         return torch.from_numpy(words.view(np.int32))
 
-    def gather_buffer(self, n_words):
+    def gather_buffer(self, n_words, buffer=0):
         return torch.empty(n_words, dtype=torch.int32)
 
     def process_packed(self, words_all, offsets, n_reads, n_bases):
@@ -67,7 +67,7 @@ def reads_of(step, rank, k, case):
     raise ValueError(case)
 
 
-def worker(rank, world, port, k, depth, canonical, steps, case, q):
+def worker(rank, world, port, k, depth, canonical, steps, case, ahead, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,11 +75,15 @@ def worker(rank, world, port, k, depth, canonical, steps, case, q):
         from nomalise_kmers_multi_large_amd.replicated import ReplicatedReadsNormaliser
         rn = ReplicatedReadsNormaliser(CheckerReplicaEngine(k, depth, canonical, world, rank))
         out = []
+        batches = []
         for step in range(steps):
-            reads = reads_of(step, rank, k, case)
-            seq, off = concat(reads)
-            high, total, gathered = rn.process_step(torch.from_numpy(seq), torch.from_numpy(off), len(reads), len(seq))
-            assert high.shape[0] == len(reads) and (gathered is None) == (rank != 0)
+            seq, off = concat(reads_of(step, rank, k, case))
+            batches.append((torch.from_numpy(seq), torch.from_numpy(off), len(off) - 1, len(seq)))
+        for step in range(steps):
+            # with look-ahead the next step's reads are exchanged before this step is counted
+            then = batches[step + 1] if ahead and step + 1 < steps else None
+            high, total, gathered = rn.process_step(*batches[step], then=then)
+            assert high.shape[0] == batches[step][2] and (gathered is None) == (rank != 0)
             if rank == 0:
                 out.append([g.numpy().copy() for g in gathered])
         uniq = torch.tensor([rn.stats()["unique_kmers"]], dtype=torch.int64)
@@ -90,13 +94,14 @@ def worker(rank, world, port, k, depth, canonical, steps, case, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,depth,canonical,case", [(2, 9, 3, False, "ragged"), (3, 11, 2, True, "ragged"), (2, 7, 5, False, "lopsided")])
-def test_replicated_reads_equal_single_stream(oracle_lib, world, k, depth, canonical, case):
-    steps = 3
+@pytest.mark.parametrize("world,k,depth,canonical,case,ahead", [(2, 9, 3, False, "ragged", False), (3, 11, 2, True, "ragged", True),
+                                                                (2, 7, 5, False, "lopsided", False), (2, 7, 5, False, "lopsided", True)])
+def test_replicated_reads_equal_single_stream(oracle_lib, world, k, depth, canonical, case, ahead):
+    steps = 4
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, case, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, case, ahead, q)) for r in range(world)]
     for p in procs:
         p.start()
     got, uniq = q.get(timeout=120)
