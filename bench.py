@@ -199,10 +199,8 @@ def main():
         def step(i, last=True):
             i %= len(dev_steps)
             s, o, nr, nb = dev_steps[i]
-            if multi_mode == "replicated":  # the next step's reads are exchanged while this step is counted
-                _, _, gathered = eng.process_step(s, o, nr, nb, then=None if last else dev_steps[(i + 1) % len(dev_steps)])
-            else:
-                _, _, gathered = eng.process_step(s, o, nr, nb)
+            # the next step's reads (or k-mers) are exchanged while this step is counted
+            _, _, gathered = eng.process_step(s, o, nr, nb, then=None if last else dev_steps[(i + 1) % len(dev_steps)])
             if rank == 0:  # keep/skip for the whole step, in global stream order (rank-major)
                 for r, buf in enumerate(gathered):
                     engine.decide(buf[0], buf[1], buf.shape[1] // 2, True, d_keep_all[i, r])

@@ -36,10 +36,12 @@ class HipShardEngine:
         self.key_dtype = torch.int32 if self.nk.key_bytes == 4 else torch.int64
         npos = (max_bases + 15) // 16 * 16
         self.keys = torch.zeros(npos, dtype=self.key_dtype, device=self.dev)
-        self.send_keys = torch.zeros(npos, dtype=self.key_dtype, device=self.dev)
-        self.send_src = torch.zeros(npos, dtype=torch.int32, device=self.dev)
+        # two sets of what the key exchange touches: the next step's keys travel while this step's are counted
+        self.send_keys2 = [torch.zeros(npos, dtype=self.key_dtype, device=self.dev) for _ in range(2)]
+        self.send_src2 = [torch.zeros(npos, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.recv_keys2 = [torch.zeros(self.cap, dtype=self.key_dtype, device=self.dev) for _ in range(2)]
+        self.send_keys, self.send_src, self.recv_keys = self.send_keys2[0], self.send_src2[0], self.recv_keys2[0]
         self.flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
-        self.recv_keys = torch.zeros(self.cap, dtype=self.key_dtype, device=self.dev)
         self.recv_flags = torch.zeros(self.cap, dtype=torch.uint8, device=self.dev)
         self.back_flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
         self.high = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
@@ -53,6 +55,10 @@ class HipShardEngine:
         counts = self.nk.route_keys_device(keys.data_ptr(), keys.numel(), n_shards, self.send_keys.data_ptr(), self.send_src.data_ptr())
         n = sum(counts)
         return self.send_keys[:n], self.send_src[:n], counts
+
+    def use_buffers(self, which):
+        """Which of the two sets of exchange buffers kmerise_route / route / recv_buffer hand out from now on."""
+        self.send_keys, self.send_src, self.recv_keys = self.send_keys2[which], self.send_src2[which], self.recv_keys2[which]
 
     def kmerise_route(self, seq, offsets, n_reads, n_bases, n_shards):
         """kmerise + route in one go: the k-mers are recomputed from the packed reads by the routing passes
@@ -68,11 +74,13 @@ class HipShardEngine:
         return self.recv_keys[:n]
 
     def count(self, recv_keys):
+        """recv_keys: what recv_buffer returned, filled (the buffer behind it is padded to a multiple of 16 keys here)."""
         n = recv_keys.numel()
         n16 = (n + 15) // 16 * 16
+        whole = next(b for b in self.recv_keys2 if b.data_ptr() == recv_keys.data_ptr()) if n else self.recv_keys
         if n16 > n:
-            self.recv_keys[n:n16].zero_()
-        self.nk.count_keys_device(self.recv_keys.data_ptr(), n16, self.recv_flags.data_ptr())
+            whole[n:n16].zero_()
+        self.nk.count_keys_device(whole.data_ptr(), n16, self.recv_flags.data_ptr())
         return self.recv_flags[:n]
 
     def back_buffer(self, n):
@@ -112,38 +120,56 @@ class ShardedNormaliser:
         # one device) by bouncing the exchanged buffers through host memory
         self.stage_through_host = stage_through_host
         self.max_message_bytes = max_message_bytes
+        self._buffer = 0      # which of the engine's two sets of exchange buffers the next step uses
+        self._ahead = None    # the exchange started for the step announced by `then`
 
-    def _all_to_all(self, out, inp, out_splits, in_splits, peak):
+    def _all_to_all_start(self, out, inp, out_splits, in_splits, peak):
         """out/inp: per-peer segments back to back.  `peak` is the largest segment anywhere in the job (the same
         number on every rank); segments are exchanged in rounds of at most max_message_bytes each, because one
-        message of more than 1024 MiB arrives cut in half through all_to_all_single on this stack (RCCL 2.26.6 of torch 2.10+rocm7.0; tools/rccl_msg_check.py: 1024 MiB whole, 1025 MiB half lost)."""
+        message of more than 1024 MiB arrives cut in half through all_to_all_single on this stack (RCCL 2.26.6 of torch 2.10+rocm7.0; tools/rccl_msg_check.py: 1024 MiB whole, 1025 MiB half lost).
+        The collectives are left in flight: returns a list of (handle to wait for or None, what to do after it or None)."""
         limit = max(1, self.max_message_bytes // inp.element_size())
         rounds = max(1, -(-peak // limit))
         if rounds == 1:
-            self._all_to_all_once(out, inp, out_splits, in_splits)
-            return
+            return [(self._all_to_all_once(out, inp, out_splits, in_splits), None, (out, inp))]
         in_at = np.concatenate([[0], np.cumsum(in_splits)])
         out_at = np.concatenate([[0], np.cumsum(out_splits)])
+        owed = []
         for r in range(rounds):
             lo = r * limit
             isz = [int(min(max(n - lo, 0), limit)) for n in in_splits]
             osz = [int(min(max(n - lo, 0), limit)) for n in out_splits]
             piece_in = torch.cat([inp[int(in_at[p]) + lo: int(in_at[p]) + lo + isz[p]] for p in range(self.world)])
             piece_out = torch.empty(sum(osz), dtype=out.dtype, device=out.device)
-            self._all_to_all_once(piece_out, piece_in, osz, isz)
-            at = 0
-            for p in range(self.world):
-                out[int(out_at[p]) + lo: int(out_at[p]) + lo + osz[p]].copy_(piece_out[at: at + osz[p]])
-                at += osz[p]
+            work = self._all_to_all_once(piece_out, piece_in, osz, isz)
+
+            def place(piece_out=piece_out, osz=osz, lo=lo):
+                at = 0
+                for p in range(self.world):
+                    out[int(out_at[p]) + lo: int(out_at[p]) + lo + osz[p]].copy_(piece_out[at: at + osz[p]])
+                    at += osz[p]
+            owed.append((work, place, (piece_in, piece_out)))
+        return owed
+
+    @staticmethod
+    def _all_to_all_finish(owed):
+        for work, after, _alive in owed:
+            if work is not None:
+                work.wait()
+            if after is not None:
+                after()
+
+    def _all_to_all(self, out, inp, out_splits, in_splits, peak):
+        self._all_to_all_finish(self._all_to_all_start(out, inp, out_splits, in_splits, peak))
 
     def _all_to_all_once(self, out, inp, out_splits, in_splits):
         if not self.stage_through_host or not inp.is_cuda:
-            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
-            return
+            return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
         self.eng.synchronize()
         h_out = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(h_out, inp.cpu(), out_splits, in_splits, group=self.group)
         out.copy_(h_out)
+        return None
 
     def _p2p_gather(self, packed, sizes):
         host = self.stage_through_host and packed.is_cuda
@@ -167,30 +193,52 @@ class ShardedNormaliser:
         dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=self.group)
         return [int(x) for x in rc.tolist()], int(peak.item())
 
-    def process_step(self, seq, offsets, n_reads, n_bases):
-        """seq/offsets: this rank's reads (device tensors for the HIP engine).  Returns (high, total) of this
-        rank's reads, and on rank 0 additionally the gathered (high_all, total_all) lists per rank."""
+    def _start_exchange(self, seq, offsets, n_reads, n_bases):
+        """Everything of a step that does not need the table: k-mers, routing, the all-to-all of keys (left in flight)."""
         eng, W = self.eng, self.world
+        self._buffer ^= 1
+        if hasattr(eng, "use_buffers"):
+            eng.use_buffers(self._buffer)
+        x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases)}
         if hasattr(eng, "kmerise_route"):
-            send_keys, send_src, send_counts, n_positions = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
+            send_keys, x["send_src"], x["send_counts"], x["n_positions"] = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
         else:
             keys = eng.kmerise(seq, offsets, n_reads, n_bases)
-            send_keys, send_src, send_counts = eng.route(keys, W)
-            n_positions = keys.numel()
-        recv_counts, peak = self._exchange_counts(send_counts, send_keys)
-        recv_keys = eng.recv_buffer(sum(recv_counts))
-        self._all_to_all(recv_keys, send_keys, recv_counts, send_counts, peak)
-        recv_flags = eng.count(recv_keys)
-        back = eng.back_buffer(sum(send_counts))
-        self._all_to_all(back, recv_flags, send_counts, recv_counts, peak)
-        flags = eng.unroute(back, send_src, n_positions)
+            send_keys, x["send_src"], x["send_counts"] = eng.route(keys, W)
+            x["n_positions"] = keys.numel()
+        x["recv_counts"], x["peak"] = self._exchange_counts(x["send_counts"], send_keys)
+        x["recv_keys"] = eng.recv_buffer(sum(x["recv_counts"]))
+        x["owed"] = self._all_to_all_start(x["recv_keys"], send_keys, x["recv_counts"], x["send_counts"], x["peak"])
+        x["alive"] = (send_keys, seq, offsets)
+        return x
+
+    def process_step(self, seq, offsets, n_reads, n_bases, then=None):
+        """seq/offsets: this rank's reads (device tensors for the HIP engine).  Returns (high, total) of this
+        rank's reads, and on rank 0 additionally the gathered (high_all, total_all) lists per rank.
+        then = (seq, offsets, n_reads, n_bases) of the step that follows, if the caller has it already: its k-mers are
+        routed and sent while this step's are counted.  All ranks must pass `then` in the same steps, and the next
+        call must be for exactly that batch."""
+        eng, W = self.eng, self.world
+        key = (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases)
+        x, self._ahead = self._ahead, None
+        if x is not None and x["key"] != key:
+            raise RuntimeError("process_step was announced another batch by the previous call's `then`")
+        if x is None:
+            x = self._start_exchange(seq, offsets, n_reads, n_bases)
+        self._all_to_all_finish(x["owed"])
+        if then is not None:
+            self._ahead = self._start_exchange(*then)
+        recv_flags = eng.count(x["recv_keys"])
+        back = eng.back_buffer(sum(x["send_counts"]))
+        self._all_to_all(back, recv_flags, x["send_counts"], x["recv_counts"], x["peak"])
+        flags = eng.unroute(back, x["send_src"], x["n_positions"])
         high, total = eng.reduce(flags, offsets, n_reads)
         gathered = None
         if self.gather_to_root:
             cdev = "cpu" if self.stage_through_host else high.device
             n_all = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(W)]
             dist.all_gather(n_all, torch.tensor([n_reads], dtype=torch.int64, device=cdev), group=self.group)
-            gathered = self._p2p_gather(torch.stack([high, total]), [int(x.item()) for x in n_all])
+            gathered = self._p2p_gather(torch.stack([high, total]), [int(v.item()) for v in n_all])
         return high, total, gathered
 
     def synchronize(self):

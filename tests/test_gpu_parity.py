@@ -364,11 +364,11 @@ def test_sharded_normaliser_over_rccl_world_of_one(nk):
         with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
             h = torch.zeros(2 * bp, dtype=torch.int32, device="cuda")
             t = torch.zeros_like(h)
-            for c1, c2 in synth.pair_blocks(3 * bp, seed=5, transcripts=40, block=bp):
-                seq, off = synth.interleave(c1, c2)
-                d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
-                nr, nb = len(off) - 1, len(seq)
-                high, total, gathered = sn.process_step(d_seq, d_off, nr, nb)
+            host = [synth.interleave(c1, c2) for c1, c2 in synth.pair_blocks(4 * bp, seed=5, transcripts=40, block=bp)]
+            dev = [(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq)) for seq, off in host]
+            for i, (d_seq, d_off, nr, nb) in enumerate(dev):
+                # steps 0 and 1 announce their successor (its keys travel while this step's are counted), step 2 does not
+                high, total, gathered = sn.process_step(d_seq, d_off, nr, nb, then=dev[i + 1] if i < 2 else None)
                 g.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, nb, h.data_ptr(), t.data_ptr())
                 sn.synchronize()
                 g.synchronize()
@@ -424,10 +424,12 @@ def _two_rank_worker(rank, world, port, steps, bp, q):
         eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, slack=2.0)
         sn = ShardedNormaliser(eng, stage_through_host=True, max_message_bytes=4 << 20)
         blocks = list(synth.pair_blocks(steps * bp, seed=11 + rank, transcripts=30, block=bp))
-        out = []
+        out, batches = [], []
         for c1, c2 in blocks:
             seq, off = synth.interleave(c1, c2)
-            high, total, gathered = sn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq))
+            batches.append((torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq)))
+        for i, b in enumerate(batches):   # the first step announces the second (keys sent ahead), the others do not
+            high, total, gathered = sn.process_step(*b, then=batches[1] if i == 0 else None)
             sn.synchronize()
             if rank == 0:
                 out.append([g.cpu().numpy().copy() for g in gathered])

@@ -79,18 +79,22 @@ def concat(reads):
     return np.frombuffer(b"".join(reads), dtype=np.uint8).copy(), off
 
 
-def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=256 << 20):
+def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=256 << 20, ahead=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
         sn = ShardedNormaliser(CheckerEngine(k, depth, canonical), max_message_bytes=max_message_bytes)
-        out = []
+        out, batches = [], []
         for step in range(steps):
             reads = make_reads(100 * step + rank, 40 + 7 * rank, k, 90)   # ragged: ranks bring different amounts
             seq, off = concat(reads)
-            high, total, gathered = sn.process_step(torch.from_numpy(seq), torch.from_numpy(off), len(reads), len(seq))
+            batches.append((torch.from_numpy(seq), torch.from_numpy(off), len(reads), len(seq)))
+        for step in range(steps):
+            # with look-ahead the next step's keys are exchanged before this step's are counted
+            then = batches[step + 1] if ahead and step + 1 < steps else None
+            high, total, gathered = sn.process_step(*batches[step], then=then)
             if rank == 0:
                 out.append([g.numpy().copy() for g in gathered])
         uniq = torch.tensor([sn.stats()["unique_kmers"]], dtype=torch.int64)
@@ -110,14 +114,16 @@ def free_port():
 
 
 # the last case exchanges in rounds of at most 1000 bytes per message (several rounds per step)
-@pytest.mark.parametrize("world,k,depth,canonical,msg", [(2, 9, 3, False, 256 << 20), (2, 21, 2, True, 256 << 20), (3, 11, 4, True, 256 << 20),
-                                                         (2, 11, 3, True, 1000)])
-def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg):
+# and the last two send the next step's keys ahead of the current step's counting
+@pytest.mark.parametrize("world,k,depth,canonical,msg,ahead", [(2, 9, 3, False, 256 << 20, False), (2, 21, 2, True, 256 << 20, False),
+                                                               (3, 11, 4, True, 256 << 20, False), (2, 11, 3, True, 1000, False),
+                                                               (3, 11, 4, True, 256 << 20, True), (2, 11, 3, True, 1000, True)])
+def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg, ahead):
     steps = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg, ahead)) for r in range(world)]
     for p in procs:
         p.start()
     got, uniq = q.get(timeout=120)

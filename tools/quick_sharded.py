@@ -20,9 +20,10 @@ for c1, c2 in synth.pair_blocks(n, seed=1, transcripts=max(50, n // 1000), block
 eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, profile=(os.environ.get("PROF", "1") == "1"))
 sn = ShardedNormaliser(eng)
 keep = torch.zeros(bp, dtype=torch.uint8, device="cuda")
+AHEAD = os.environ.get("AHEAD", "1") == "1"   # send the next step's keys while this step's are counted
 for i, (s, o, nr, nb) in enumerate(batches):
     torch.cuda.synchronize(); t = time.time()
-    high, total, gathered = sn.process_step(s, o, nr, nb)
+    high, total, gathered = sn.process_step(s, o, nr, nb, then=batches[i + 1] if AHEAD and i + 1 < len(batches) else None)
     eng.decide(gathered[0][0], gathered[0][1], nr // 2, True, keep)
     sn.synchronize(); torch.cuda.synchronize()
     dt = time.time() - t
