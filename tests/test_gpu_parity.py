@@ -671,3 +671,45 @@ def test_replicated_normaliser_over_rccl_world_of_one(nk):
             assert seen > 0 and eng.stats()["unique_kmers"] == g.unique_kmers
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [15, 13, 25])
+def test_one_batch_of_more_than_two_to_the_31_positions(nk, k):
+    """2.4 G base positions (8 M pairs) in ONE batch - positions, key arrays (9.6 GB) and sorted-position arrays well past
+    2^31 entries / 2^32 bytes - against the same reads handed over in four batches of 2 M pairs: the per-read counters
+    and the number of distinct k-mers must not depend on the cut (the small batches are covered against the oracle and the
+    known answer elsewhere)."""
+    import torch
+    from nomalise_kmers_multi_large_amd import binding, synth
+    quarter, copies = 2000000, 4
+    blocks = list(synth.pair_blocks(quarter, seed=1, transcripts=2000))
+    seq, off = synth.interleave(np.concatenate([b[0] for b in blocks]), np.concatenate([b[1] for b in blocks]))
+    del blocks
+    nr, nb = len(off) - 1, len(seq)
+    # four different quarters from one: quarter j is the first one rotated by j reads (mates stay together only for j even, which
+    # does not matter to the per-read counters)
+    d_seq1, d_off1 = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+    assert (np.diff(off) == 150).all()
+    parts = [torch.roll(d_seq1.view(nr, 150), shifts=j * 7919, dims=0).reshape(-1) for j in range(copies)]
+    d_seq = torch.cat(parts)
+    d_off = torch.arange(0, copies * nr + 1, dtype=torch.int64, device="cuda") * 150
+    assert d_seq.numel() == copies * nb > (1 << 31)
+    # k=15: partitioned path in both; k=13: atomic path on the direct table; k=25: hashed table, canonical, growing
+    big = nk.KmerNormaliser(k, 100, 0.9, k == 25, max_batch_reads=copies * nr, max_batch_bases=copies * nb,
+                            flags=binding.NKML_F_COUNT_PARTITIONED if k == 15 else 0)
+    small = nk.KmerNormaliser(k, 100, 0.9, k == 25, max_batch_reads=nr, max_batch_bases=nb)
+    try:
+        assert big.stats()["partitioned"] == small.stats()["partitioned"] == (1 if k == 15 else 0)
+        out_big = torch.zeros((2, copies * nr), dtype=torch.int32, device="cuda")
+        out_small = torch.zeros((2, copies * nr), dtype=torch.int32, device="cuda")
+        big.process_device(d_seq.data_ptr(), d_off.data_ptr(), copies * nr, copies * nb, out_big[0].data_ptr(), out_big[1].data_ptr())
+        for j in range(copies):
+            small.process_device(parts[j].data_ptr(), d_off1.data_ptr(), nr, nb, out_small[0, j * nr:].data_ptr(), out_small[1, j * nr:].data_ptr())
+        big.synchronize()
+        small.synchronize()
+        assert torch.equal(out_big, out_small)
+        assert int(out_big[0].sum()) > 0 and int(out_big[0].sum()) < int(out_big[1].sum())
+        assert big.unique_kmers == small.unique_kmers
+    finally:
+        big.close()
+        small.close()
