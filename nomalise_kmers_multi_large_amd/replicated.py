@@ -118,7 +118,7 @@ class HipReplicaEngine:
 class ReplicatedReadsNormaliser:
     """Same face as ShardedNormaliser: one step = every rank's batch, processed as one global batch in rank-major order."""
 
-    def __init__(self, engine, group=None, stage_through_host=False):
+    def __init__(self, engine, group=None, stage_through_host=False, check_words=None):
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group)
@@ -127,6 +127,29 @@ class ReplicatedReadsNormaliser:
         self.stage_through_host = stage_through_host
         self._buffer = 0      # which of the engine's two sets of exchange buffers the next step uses
         self._ahead = None    # the exchange started for the step announced by `then`
+        if check_words is None:
+            check_words = int(getattr(engine, "max_region", 0))
+        if check_words:
+            self.check_collectives(check_words, getattr(engine, "dev", "cpu"))
+
+    def check_collectives(self, n, device):
+        """The two collectives of a step at the largest size this job uses (n words per rank), with known content: a
+        stack that delivers something else than what was sent must stop the job, not change its results."""
+        W, me = self.world, self.rank
+        mine = torch.arange(n, dtype=torch.int32, device=device) + 7919 * me
+        out = torch.zeros(W * n, dtype=torch.int32, device=device)
+        work = self._gather_equal(out, mine, async_op=True)
+        if work is not None:
+            work.wait()
+        ok = all(bool(torch.equal(out[p * n:(p + 1) * n], mine + 7919 * (p - me))) for p in range(W))
+        ones = torch.ones(min(2 * n, 1 << 26), dtype=torch.int32, device=device)
+        self._sum(ones)
+        ok = ok and bool((ones == W).all())
+        cdev = "cpu" if self.stage_through_host or str(device) == "cpu" else device
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if not int(flag.item()):
+            raise RuntimeError("all-gather / sum of %d words per rank does not deliver what was sent" % n)
 
     def _gather_equal(self, out, inp, async_op=False):
         """all-gather of equal pieces; with async_op the returned handle's wait() is owed before `out` is used."""

@@ -35,6 +35,7 @@ class HipShardEngine:
         self.nk.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.key_dtype = torch.int32 if self.nk.key_bytes == 4 else torch.int64
         npos = (max_bases + 15) // 16 * 16
+        self.max_positions = npos
         self.keys = torch.zeros(npos, dtype=self.key_dtype, device=self.dev)
         # two sets of what the key exchange touches: the next step's keys travel while this step's are counted
         self.send_keys2 = [torch.zeros(npos, dtype=self.key_dtype, device=self.dev) for _ in range(2)]
@@ -110,7 +111,7 @@ class HipShardEngine:
 class ShardedNormaliser:
     """One step = every rank's batch of reads, processed as one global batch (rank-major stream order)."""
 
-    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=512 << 20):
+    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=768 << 20, check_elems=None):
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group)
@@ -122,6 +123,38 @@ class ShardedNormaliser:
         self.max_message_bytes = max_message_bytes
         self._buffer = 0      # which of the engine's two sets of exchange buffers the next step uses
         self._ahead = None    # the exchange started for the step announced by `then`
+        # Start-up check of the exchange with messages as large as this job can send (see check_exchange): elements per
+        # peer, None = from the engine's sizes, 0 = no check
+        if check_elems is None:
+            check_elems = -(-int(getattr(engine, "max_positions", 0)) * 5 // (4 * self.world))
+        if check_elems:
+            self.check_exchange(check_elems, getattr(engine, "key_dtype", torch.int64), getattr(engine, "dev", "cpu"))
+
+    def check_exchange(self, n, dtype, device):
+        """One all-to-all with known content and n elements for every peer, through the same rounds as the real exchange.
+        A stack that loses part of a large message (seen with one message of more than 1024 MiB) must not go unnoticed:
+        if what arrives is not what was sent, max_message_bytes is halved (more rounds) and the check repeated; after
+        three failures the job stops."""
+        W, me = self.world, self.rank
+        n = int(n)
+        for attempt in range(4):
+            src = torch.arange(W * n, dtype=torch.int64, device=device)
+            src = (src + 7919 * me).to(dtype)
+            out = torch.zeros_like(src)
+            self._all_to_all(out, src, [n] * W, [n] * W, n)
+            ok = True
+            for p in range(W):   # rank p sent its segment number `me`
+                want = (torch.arange(me * n, (me + 1) * n, dtype=torch.int64, device=device) + 7919 * p).to(dtype)
+                ok = ok and bool(torch.equal(out[p * n:(p + 1) * n], want))
+            del src, out
+            cdev = "cpu" if self.stage_through_host or str(device) == "cpu" else device
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if int(flag.item()):
+                return
+            self.max_message_bytes //= 2
+        raise RuntimeError("all-to-all of %d elements per peer does not deliver what was sent, even in rounds of %d bytes"
+                           % (n, self.max_message_bytes * 2))
 
     def _all_to_all_start(self, out, inp, out_splits, in_splits, peak):
         """out/inp: per-peer segments back to back.  `peak` is the largest segment anywhere in the job (the same

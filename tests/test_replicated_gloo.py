@@ -73,7 +73,7 @@ def worker(rank, world, port, k, depth, canonical, steps, case, ahead, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.replicated import ReplicatedReadsNormaliser
-        rn = ReplicatedReadsNormaliser(CheckerReplicaEngine(k, depth, canonical, world, rank))
+        rn = ReplicatedReadsNormaliser(CheckerReplicaEngine(k, depth, canonical, world, rank), check_words=5000)
         out = []
         batches = []
         for step in range(steps):

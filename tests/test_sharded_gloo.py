@@ -85,7 +85,9 @@ def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=2
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
-        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical), max_message_bytes=max_message_bytes)
+        # with small messages also run the start-up check of the exchange (3000 elements per peer, many rounds)
+        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical), max_message_bytes=max_message_bytes, check_elems=3000 if max_message_bytes < 4096 else 0)
+        assert sn.max_message_bytes == max_message_bytes
         out, batches = [], []
         for step in range(steps):
             reads = make_reads(100 * step + rank, 40 + 7 * rank, k, 90)   # ragged: ranks bring different amounts
@@ -149,3 +151,30 @@ def test_owner_rule_matches_library():
     for n in (1, 2, 3, 8):
         want = owner_np(keys, n)
         assert [lib.nkml_owner_of(int(x), n) for x in keys] == want.tolist()
+
+
+def test_startup_check_notices_a_lossy_exchange_and_shrinks_the_rounds():
+    """A transport that drops the second half of every message above 4000 bytes (what was seen with RCCL above 1024 MiB):
+    the start-up check halves max_message_bytes until messages arrive whole; one that always loses data stops the job."""
+    from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        class Lossy(ShardedNormaliser):
+            threshold = 4000
+
+            def _all_to_all_once(self, out, inp, out_splits, in_splits):
+                work = super()._all_to_all_once(out, inp, out_splits, in_splits)
+                if work is not None:
+                    work.wait()
+                if inp.numel() * inp.element_size() > self.threshold:
+                    out[out.numel() // 2:] = 0
+                return None
+
+        sn = Lossy(CheckerEngine(9, 3, False), max_message_bytes=12000, check_elems=2000)   # 16000 bytes per peer
+        assert sn.max_message_bytes == 3000
+        Lossy.threshold = 0
+        with pytest.raises(RuntimeError):
+            Lossy(CheckerEngine(9, 3, False), max_message_bytes=12000, check_elems=2000)
+    finally:
+        dist.destroy_process_group()
