@@ -1615,6 +1615,8 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         if (cfg->flags & NKML_F_COUNT_ATOMIC) want = false;
         c->partitioned = can && want;
     }
+    c->n_shards = 1; // (the memset above also wiped the member initialisers)
+    c->shard = 0;
     c->key_bytes = c->direct ? 4 : 8;
     uint32_t chunk = cfg->chunk_bases ? cfg->chunk_bases : (32u << 20);
     chunk = (chunk + 63) & ~63u;
