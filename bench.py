@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): synthetic 150 bp paired-end reads, k=15, depth=100, coverage=0.9, one
+Workload (the 10 M-read single-GPU configuration of the headline metric): synthetic 150 bp paired-end reads, k=15, depth=100, coverage=0.9, one
 device-resident k-mer table.  A step is one batch of --pairs-per-step read pairs (default 2 M) taken in stream
 order from the synthetic dataset; with the default 5 steps the timed region is the whole 10 M-pair
 dataset starting from an empty table.  Inputs are resident in HBM before the clock starts.  The per-step work is
@@ -13,10 +13,12 @@ the complete hot path: pack -> k-mers -> count with exact stream-order ranks -> 
 keep/skip decision.  At k=15 the library counts by radix-partitioning each batch's k-mers into buckets that are
 counted in LDS (NKML_PARTITIONED=0 selects the atomic path instead).
 
-With N > 1 ranks the k-mer table is sharded by k-mer over the ranks: every rank k-merises its own slice of
-each step's pairs, keys travel to their owning rank with an all-to-all (RCCL), the owner counts them, the
-flags travel back, and the per-read counters are reduced where the reads live ("weak" scaling: each rank
-brings --pairs-per-step pairs per step).
+With N > 1 ranks the k-mer table is sharded by k-mer over the ranks ("weak" scaling: each rank brings
+--pairs-per-step pairs per step, and the step's result is that of one table reading rank 0's pairs, then rank 1's, ...).
+On 2-3 ranks every rank gets all packed reads of the step (one all-gather) and counts the k-mers of its own shard; beyond
+that the k-mers travel to their owning rank with an all-to-all (RCCL), the owner counts them and the flags travel back.
+Either way the per-read counters end on rank 0, which takes the keep/skip decisions (NKML_MULTI_GPU=replicated|exchange
+overrides the choice).
 
 One JSON line is printed by rank 0.
 """
