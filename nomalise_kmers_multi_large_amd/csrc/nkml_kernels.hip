@@ -91,16 +91,32 @@ __global__ void __launch_bounds__(256) k_mark_starts(const uint64_t *__restrict_
 // Each lane turns one 16-byte load into one 4-byte store; both sides are fully coalesced, so nothing is
 // staged through LDS.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pack4(uint32_t v, uint32_t &bad)
+__device__ __forceinline__ uint32_t pack4(uint32_t v)
 {
     // A=0x41 C=0x43 G=0x47 T=0x54 N=0x4e : ((c>>1)^(c>>2))&3 -> 0,1,2,3,0
     uint32_t x = ((v >> 1) ^ (v >> 2)) & 0x03030303u;
+    return (x * 0x40100401u) >> 24; // byte 0 (first base) lands in the top two bits of the result byte
+}
+
+// Alphabet check of four bytes at once (the kernel is bound by its instruction count, not by memory): all of ACGTN
+// sit in 0x40-0x5f, where the low five bits tell them apart - bit (c & 31) of a 32-bit set, and a shift takes its
+// amount modulo 32 by itself.
+__device__ __forceinline__ bool all_acgtn(uint32_t v)
+{
+    constexpr uint32_t SET = (1u << ('A' & 31)) | (1u << ('C' & 31)) | (1u << ('G' & 31)) | (1u << ('T' & 31)) | (1u << ('N' & 31));
+    const uint32_t in_set = (SET >> (v & 31u)) & (SET >> ((v >> 8) & 31u)) & (SET >> ((v >> 16) & 31u)) & (SET >> ((v >> 24) & 31u));
+    return (v & 0xe0e0e0e0u) == 0x40404040u && (in_set & 1u);
+}
+
+__device__ __forceinline__ uint32_t count_bad4(uint32_t v)
+{
+    uint32_t bad = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         uint32_t c = (v >> (8 * b)) & 0xffu;
         bad += !(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N');
     }
-    return (x * 0x40100401u) >> 24; // byte 0 (first base) lands in the top two bits of the result byte
+    return bad;
 }
 
 __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, uint64_t n_bases,
@@ -127,8 +143,10 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, u
                 v[i] = x;
             }
         }
-        uint32_t word = (pack4(v[0], bad) << 24) | (pack4(v[1], bad) << 16) | (pack4(v[2], bad) << 8) | pack4(v[3], bad);
+        uint32_t word = (pack4(v[0]) << 24) | (pack4(v[1]) << 16) | (pack4(v[2]) << 8) | pack4(v[3]);
         packed[w] = word;
+        if (!(all_acgtn(v[0]) && all_acgtn(v[1]) && all_acgtn(v[2]) && all_acgtn(v[3]))) // rare: count them one by one
+            bad = count_bad4(v[0]) + count_bad4(v[1]) + count_bad4(v[2]) + count_bad4(v[3]);
     }
     if (bad) atomicAdd(&ctr->bad_bases, bad);
 }
