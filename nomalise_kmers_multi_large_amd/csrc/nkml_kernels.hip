@@ -160,10 +160,67 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, u
 // ------------------------------------------------------------------------------------------------------
 // The 16 keys of packed word w.  Every lane of the wavefront must call it (shuffles); lanes with live == false
 // get zeros.  Consecutive lanes must hold consecutive words.
+// reverses the order of the sixteen 2-bit groups of a word
+__device__ __forceinline__ uint32_t reverse_pairs(uint32_t x)
+{
+    const uint32_t y = __brev(x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+
+// k <= 16: the 16 windows of a word lie within the word and its successor, so every code is one 32-bit funnel shift of
+// the pair (the reverse-complement codes likewise, of the pair complemented and reversed once), and the validity of all
+// 16 windows comes out of one bit-parallel pass over the start bits - about a third of the instructions of the rolling
+// 64-bit form below, which matters because the kernels that recompute keys from packed words are bound by them.
+template <bool CANON>
+__device__ __forceinline__ void word_keys32(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits, uint64_t w,
+                                            bool live, uint64_t n_bases, int k, uint32_t (&out)[16])
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t w0 = live ? packed[w] : 0u;   // packed/startbits carry 4 zero words of halo
+    const uint32_t s0 = live ? startbits[w] : 0u;
+    uint32_t w1 = __shfl_down(w0, 1), s1 = __shfl_down(s0, 1);
+    if (live && lane == 63) { w1 = packed[w + 1]; s1 = startbits[w + 1]; }
+    if (!live) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) out[j] = 0u;
+        return;
+    }
+    // windows without a read start after their first base: start bit j+i clear for i = 1..k-1
+    const uint32_t m = (uint32_t)k - 1u;
+    uint32_t inside = 0;
+    if (m) {
+        inside = ((s0 & 0xffffu) | (s1 << 16)) >> 1;
+        uint32_t s = 1;
+        while (2 * s <= m) { inside |= inside >> s; s <<= 1; }
+        inside |= inside >> (m - s);
+    }
+    // ... and that end within the batch: j + k <= rem
+    const uint64_t rem = n_bases - w * 16;
+    const uint32_t fits = rem >= (uint64_t)(15 + k) ? 0xffffu : (rem < (uint64_t)k ? 0u : (2u << (uint32_t)(rem - (uint64_t)k)) - 1u);
+    const uint32_t ok = ~inside & fits;
+    const int down = 32 - 2 * k;
+    const uint32_t mask = k == 16 ? 0xffffffffu : (1u << (2 * k)) - 1u;
+    uint32_t r0 = 0, r1 = 0;
+    if (CANON) { r0 = reverse_pairs(~w0); r1 = reverse_pairs(~w1); } // complement of base p at bits 2p, 2p+1 of r1:r0
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t code = (j == 0 ? w0 : __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * j)) >> down;
+        if (CANON) {
+            const uint32_t rc = (j == 0 ? r0 : __builtin_amdgcn_alignbit(r1, r0, 2 * j)) & mask;
+            code = rc < code ? rc : code;
+        }
+        out[j] = ((ok >> j) & 1u) ? code : 0u;
+    }
+}
+
 template <typename KEY, bool CANON>
 __device__ __forceinline__ void word_keys(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits, uint64_t w,
                                           bool live, uint64_t n_bases, int k, KEY (&out)[16])
 {
+    if constexpr (sizeof(KEY) == 4) { // 32-bit keys are only used for k <= 16
+        word_keys32<CANON>(packed, startbits, w, live, n_bases, k, out);
+        return;
+    }
     int lane = threadIdx.x & 63;
     uint32_t w0 = live ? packed[w] : 0u;         // packed/startbits carry 4 zero words of halo
     uint32_t s0 = live ? startbits[w] : 0u;
