@@ -34,7 +34,7 @@ def fits(ksize, depth, world, max_bases):
 def step_layout(n_reads, n_bases):
     """Host-side plan of one step from every rank's (reads, bases): region size in words, per rank the number of
     filler reads and the index of its first read in the global read list, and the total number of reads."""
-    region = max((int(b) + 15) // 16 for b in n_bases)
+    region = max(1, max((int(b) + 15) // 16 for b in n_bases))   # at least one word, so that a step nobody brings reads to stays an ordinary step
     fillers, first, at = [], [], 0
     for r, b in zip(n_reads, n_bases):
         gap = region * 16 - int(b)
@@ -88,7 +88,8 @@ class HipReplicaEngine:
         if region > self.max_region or nw > region:
             raise RuntimeError("step of %d words per rank, sized for %d" % (region, self.max_region))
         words = self.words[buffer]
-        self.nk.pack_device(seq.data_ptr(), n_bases, words.data_ptr())
+        if n_bases:   # a rank may have nothing to bring to a step
+            self.nk.pack_device(seq.data_ptr(), n_bases, words.data_ptr())
         if region > nw:
             words[nw:region].zero_()
         return words[:region]

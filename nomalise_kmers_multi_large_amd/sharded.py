@@ -64,6 +64,8 @@ class HipShardEngine:
     def kmerise_route(self, seq, offsets, n_reads, n_bases, n_shards):
         """kmerise + route in one go: the k-mers are recomputed from the packed reads by the routing passes
         themselves, no key array is written.  Returns (send_keys, send_src, counts, n_positions)."""
+        if n_reads == 0:   # a rank may have nothing to bring to a step
+            return self.send_keys[:0], self.send_src[:0], [0] * n_shards, 0
         counts = self.nk.route_reads_device(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, n_shards,
                                             self.send_keys.data_ptr(), self.send_src.data_ptr())
         n = sum(counts)
@@ -92,6 +94,8 @@ class HipShardEngine:
         return self.flags[:n_positions]
 
     def reduce(self, flags, offsets, n_reads):
+        if n_reads == 0:
+            return self.high[:0], self.total[:0]
         self.nk.reduce_reads_device(self.keys.data_ptr(), flags.data_ptr(), offsets.data_ptr(), n_reads, self.high.data_ptr(), self.total.data_ptr())
         return self.high[:n_reads], self.total[:n_reads]
 

@@ -713,3 +713,41 @@ def test_one_batch_of_more_than_two_to_the_31_positions(nk, k):
     finally:
         big.close()
         small.close()
+
+
+@pytest.mark.parametrize("mode", ["replicated", "exchange"])
+def test_multi_gpu_step_to_which_a_rank_brings_nothing(nk, mode):
+    """Both multi-GPU normalisers over RCCL (world of one): a step without any read between two ordinary steps returns
+    empty counters and leaves the table alone; the ordinary steps equal the single-table path."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.replicated import make_multi_gpu_normaliser
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bp = 8000
+        mg, engine, chosen = make_multi_gpu_normaliser(15, 20, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, mode=mode)
+        assert chosen == mode
+        host = [synth.interleave(c1, c2) for c1, c2 in synth.pair_blocks(2 * bp, seed=3, transcripts=10, block=bp)]
+        empty = (torch.zeros(0, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda"), 0, 0)
+        steps = [host[0], None, host[1]]
+        dev = [empty if h is None else (torch.from_numpy(h[0]).cuda(), torch.from_numpy(h[1].astype(np.int64)).cuda(), len(h[1]) - 1, len(h[0])) for h in steps]
+        with nk.KmerNormaliser(15, 20, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
+            for i, h in enumerate(steps):
+                high, total, gathered = mg.process_step(*dev[i], then=dev[i + 1] if i + 1 < len(dev) else None)
+                if h is None:
+                    assert high.numel() == 0 and total.numel() == 0 and gathered[0].shape[1] == 0
+                    continue
+                want_h, want_t = g.process_batch(*h)
+                np.testing.assert_array_equal(high.cpu().numpy(), want_h)
+                np.testing.assert_array_equal(total.cpu().numpy(), want_t)
+            assert mg.stats()["unique_kmers"] == g.unique_kmers and int(want_h.sum()) > 0
+    finally:
+        dist.destroy_process_group()

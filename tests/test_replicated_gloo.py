@@ -64,6 +64,8 @@ def reads_of(step, rank, k, case):
         return make_reads(100 * step + rank, 40 + 7 * rank, k, 90)
     if case == "lopsided":   # one rank brings far less than the others: its region is mostly filler
         return make_reads(100 * step + rank, 3 if rank == (step % 2) else 400, k, 120)
+    if case == "empty":      # in every step one rank has nothing at all
+        return [] if rank == (step % 2) else make_reads(100 * step + rank, 60, k, 120)
     raise ValueError(case)
 
 
@@ -95,7 +97,8 @@ def worker(rank, world, port, k, depth, canonical, steps, case, ahead, q):
 
 
 @pytest.mark.parametrize("world,k,depth,canonical,case,ahead", [(2, 9, 3, False, "ragged", False), (3, 11, 2, True, "ragged", True),
-                                                                (2, 7, 5, False, "lopsided", False), (2, 7, 5, False, "lopsided", True)])
+                                                                (2, 7, 5, False, "lopsided", False), (2, 7, 5, False, "lopsided", True),
+                                                                (2, 9, 2, True, "empty", True)])
 def test_replicated_reads_equal_single_stream(oracle_lib, world, k, depth, canonical, case, ahead):
     steps = 4
     ctx = mp.get_context("spawn")
