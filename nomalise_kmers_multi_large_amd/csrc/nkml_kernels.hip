@@ -963,7 +963,8 @@ constexpr int ROUTE_TILE = 1024;
 
 __host__ __device__ __forceinline__ uint32_t owner_of(unsigned long long key, uint32_t n_shards)
 {
-    return (uint32_t)(((key * 0x9E3779B97F4A7C15ull) >> 32) % n_shards);
+    // 32 mixed bits of the key, scaled to [0, n_shards) with a multiply (a modulo by a run-time divisor costs a division per key)
+    return (uint32_t)((((key * 0x9E3779B97F4A7C15ull) >> 32) * n_shards) >> 32);
 }
 
 // Where a routing tile's keys come from: a key array (one key per base position), or the packed words of the

@@ -17,7 +17,7 @@ OWNER_MUL = np.uint64(0x9E3779B97F4A7C15)
 
 
 def owner_np(keys, n_shards):
-    return ((keys * OWNER_MUL) >> np.uint64(32)) % np.uint64(n_shards)
+    return (((keys * OWNER_MUL) >> np.uint64(32)) * np.uint64(n_shards)) >> np.uint64(32)
 
 
 class CheckerEngine:
