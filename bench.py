@@ -195,7 +195,7 @@ def main():
     else:
         from nomalise_kmers_multi_large_amd.replicated import make_multi_gpu_normaliser
         eng, engine, multi_mode = make_multi_gpu_normaliser(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
-                                                            profile=True, stage_through_host=rehearse)
+                                                            profile=True, stage_through_host=rehearse, root_only=True)
         d_keep_all = torch.zeros((len(dev_steps), world, pps), dtype=torch.uint8, device=dev) if rank == 0 else None
 
         def step(i, last=True):

@@ -119,13 +119,14 @@ class HipReplicaEngine:
 class ReplicatedReadsNormaliser:
     """Same face as ShardedNormaliser: one step = every rank's batch, processed as one global batch in rank-major order."""
 
-    def __init__(self, engine, group=None, stage_through_host=False, check_words=None):
+    def __init__(self, engine, group=None, stage_through_host=False, check_words=None, root_only=False):
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         # rehearsal aid only (several ranks on one GPU under gloo): collectives bounce through host memory
         self.stage_through_host = stage_through_host
+        self.root_only = root_only   # only rank 0 needs the summed counters (it takes the keep/skip decisions)
         self._buffer = 0      # which of the engine's two sets of exchange buffers the next step uses
         self._ahead = None    # the exchange started for the step announced by `then`
         if check_words is None:
@@ -162,23 +163,39 @@ class ReplicatedReadsNormaliser:
             return None
         return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
-    def _sum(self, t):
+    def _sum(self, t, everywhere=True):
+        """Sum over the ranks, in place; with everywhere=False only rank 0 is owed the result (half the traffic)."""
+        op = (lambda v: dist.all_reduce(v, group=self.group)) if everywhere else (lambda v: dist.reduce(v, dst=0, group=self.group))
         if self.stage_through_host and t.is_cuda:
             self.eng.synchronize()
             h = t.cpu()
-            dist.all_reduce(h, group=self.group)
+            op(h)
             t.copy_(h)
         else:
-            dist.all_reduce(t, group=self.group)
+            op(t)
+
+    def _sum_counters(self, counters, narrow):
+        """counters: [2, reads] int32 partial (high, total) of this shard -> summed over the shards.  narrow: no read has
+        65536 k-mers or more, so both numbers travel in one 32-bit word (their sums cannot carry into each other)."""
+        everywhere = not self.root_only
+        if not narrow:
+            self._sum(counters, everywhere)
+            return
+        both = (counters[0] << 16) | counters[1]
+        self._sum(both, everywhere)
+        counters[0] = (both >> 16) & 0xffff
+        counters[1] = both & 0xffff
 
     def _start_exchange(self, seq, offsets, n_reads, n_bases):
         """Everything of a step that does not need the table: sizes, packing, the two all-gathers (left in flight)."""
         eng, W = self.eng, self.world
         cdev = "cpu" if self.stage_through_host or not seq.is_cuda else seq.device
-        meta = torch.empty(2 * W, dtype=torch.int64, device=cdev)
-        self._gather_equal(meta, torch.tensor([n_reads, n_bases], dtype=torch.int64, device=cdev))
+        longest = int((offsets[1: n_reads + 1] - offsets[:n_reads]).max()) if n_reads else 0
+        meta = torch.empty(3 * W, dtype=torch.int64, device=cdev)
+        self._gather_equal(meta, torch.tensor([n_reads, n_bases, longest], dtype=torch.int64, device=cdev))
         meta = meta.tolist()
-        x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases), "reads": meta[0::2], "bases": meta[1::2]}
+        x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases), "reads": meta[0::3], "bases": meta[1::3],
+             "narrow": max(meta[2::3]) < 65536}
         x["region"], x["fillers"], x["first"], x["total_reads"] = step_layout(x["reads"], x["bases"])
         self._buffer ^= 1
         x["words_all"] = eng.gather_buffer(W * x["region"], self._buffer)
@@ -194,7 +211,8 @@ class ReplicatedReadsNormaliser:
 
     def process_step(self, seq, offsets, n_reads, n_bases, then=None):
         """seq/offsets: this rank's reads on the device.  Returns (high, total) of this rank's reads and, on rank 0, the
-        list of [2, n_reads_r] counters of every rank's reads (views of a buffer the next step overwrites).
+        list of [2, n_reads_r] counters of every rank's reads (views of a buffer the next step overwrites); with
+        root_only the other ranks get (None, None, None): the counters are reduced to rank 0 alone.
         then = (seq, offsets, n_reads, n_bases) of the step that follows, if the caller has it already: its reads are
         packed and exchanged while this step is counted.  All ranks must pass `then` in the same steps, and the next
         call must be for exactly that batch."""
@@ -213,7 +231,9 @@ class ReplicatedReadsNormaliser:
         if then is not None:
             self._ahead = self._start_exchange(*then)
         counters = eng.process_packed(x["words_all"], goff, x["total_reads"], W * x["region"] * 16)
-        self._sum(counters)
+        self._sum_counters(counters, x["narrow"])
+        if self.root_only and self.rank != 0:
+            return None, None, None
         per_rank = [counters[:, x["first"][r]: x["first"][r] + x["reads"][r]] for r in range(W)]
         own = per_rank[self.rank]
         return own[0], own[1], (per_rank if self.rank == 0 else None)
@@ -229,7 +249,7 @@ class ReplicatedReadsNormaliser:
 
 
 def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False,
-                              stage_through_host=False, mode=None, group=None):
+                              stage_through_host=False, mode=None, group=None, root_only=False):
     """The multi-GPU normaliser that suits the job: replicated reads on two or three GPUs when a step fits one context
     (one xGMI link would carry the whole key exchange of two GPUs; measured per-rank compute of a 2 M-pair step at k=15:
     10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs, plus one all-gather of packed reads and one sum of counters), the key
@@ -241,7 +261,7 @@ def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_rea
     mode = mode or os.environ.get("NKML_MULTI_GPU") or ("replicated" if world <= 3 and fits(ksize, depth, world, max_bases) else "exchange")
     if mode == "replicated":
         engine = HipReplicaEngine(ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=profile)
-        return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host), engine, mode
+        return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host, root_only=root_only), engine, mode
     if mode != "exchange":
         raise ValueError("NKML_MULTI_GPU must be 'replicated' or 'exchange', not %r" % mode)
     engine = HipShardEngine(ksize, depth, coverage, canonical, device, max_reads=max_reads, max_bases=max_bases, profile=profile)

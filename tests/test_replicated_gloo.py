@@ -66,6 +66,10 @@ def reads_of(step, rank, k, case):
         return make_reads(100 * step + rank, 3 if rank == (step % 2) else 400, k, 120)
     if case == "empty":      # in every step one rank has nothing at all
         return [] if rank == (step % 2) else make_reads(100 * step + rank, 60, k, 120)
+    if case == "long":       # a read of 70 000 bases: its counters do not fit 16 bits, so they travel as two words
+        return make_reads(100 * step + rank, 5, k, 90) + (make_reads(7 + step, 1, 70000, 70000) if rank == 1 else [])
+    if case == "long16":     # 60 000 bases: still one word for both counters, the upper one beyond 2^15
+        return make_reads(100 * step + rank, 5, k, 90) + (make_reads(7 + step, 1, 60000, 60000) if rank == 0 else [])
     raise ValueError(case)
 
 
@@ -75,7 +79,8 @@ def worker(rank, world, port, k, depth, canonical, steps, case, ahead, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.replicated import ReplicatedReadsNormaliser
-        rn = ReplicatedReadsNormaliser(CheckerReplicaEngine(k, depth, canonical, world, rank), check_words=5000)
+        # with look-ahead also: counters reduced to rank 0 only
+        rn = ReplicatedReadsNormaliser(CheckerReplicaEngine(k, depth, canonical, world, rank), check_words=5000, root_only=ahead)
         out = []
         batches = []
         for step in range(steps):
@@ -85,7 +90,7 @@ def worker(rank, world, port, k, depth, canonical, steps, case, ahead, q):
             # with look-ahead the next step's reads are exchanged before this step is counted
             then = batches[step + 1] if ahead and step + 1 < steps else None
             high, total, gathered = rn.process_step(*batches[step], then=then)
-            assert high.shape[0] == batches[step][2] and (gathered is None) == (rank != 0)
+            assert (gathered is None) == (rank != 0) and (high is None if ahead and rank else high.shape[0] == batches[step][2])
             if rank == 0:
                 out.append([g.numpy().copy() for g in gathered])
         uniq = torch.tensor([rn.stats()["unique_kmers"]], dtype=torch.int64)
@@ -98,7 +103,7 @@ def worker(rank, world, port, k, depth, canonical, steps, case, ahead, q):
 
 @pytest.mark.parametrize("world,k,depth,canonical,case,ahead", [(2, 9, 3, False, "ragged", False), (3, 11, 2, True, "ragged", True),
                                                                 (2, 7, 5, False, "lopsided", False), (2, 7, 5, False, "lopsided", True),
-                                                                (2, 9, 2, True, "empty", True)])
+                                                                (2, 9, 2, True, "empty", True), (2, 7, 3, False, "long", True), (2, 7, 3, False, "long16", False)])
 def test_replicated_reads_equal_single_stream(oracle_lib, world, k, depth, canonical, case, ahead):
     steps = 4
     ctx = mp.get_context("spawn")
