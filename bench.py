@@ -15,7 +15,7 @@ counted in LDS (NKML_PARTITIONED=0 selects the atomic path instead).
 
 With N > 1 ranks the k-mer table is sharded by k-mer over the ranks ("weak" scaling: each rank brings
 --pairs-per-step pairs per step, and the step's result is that of one table reading rank 0's pairs, then rank 1's, ...).
-On 2-3 ranks every rank gets all packed reads of the step (one all-gather) and counts the k-mers of its own shard; beyond
+On 2-4 ranks every rank gets all packed reads of the step (one all-gather) and counts the k-mers of its own shard; beyond
 that the k-mers travel to their owning rank with an all-to-all (RCCL), the owner counts them and the flags travel back.
 Either way the per-read counters end on rank 0, which takes the keep/skip decisions (NKML_MULTI_GPU=replicated|exchange
 overrides the choice).

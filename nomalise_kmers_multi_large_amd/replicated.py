@@ -250,15 +250,16 @@ class ReplicatedReadsNormaliser:
 
 def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False,
                               stage_through_host=False, mode=None, group=None, root_only=False):
-    """The multi-GPU normaliser that suits the job: replicated reads on two or three GPUs when a step fits one context
-    (one xGMI link would carry the whole key exchange of two GPUs; measured per-rank compute of a 2 M-pair step at k=15:
-    10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs, plus one all-gather of packed reads and one sum of counters), the key
-    exchange of `sharded.py` otherwise.  `mode` or the environment variable NKML_MULTI_GPU ("replicated" / "exchange")
+    """The multi-GPU normaliser that suits the job: replicated reads on up to four GPUs when a step fits one context
+    (measured per-rank compute of a 2 M-pair step at k=15: 10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs, plus one all-gather
+    of packed reads, hidden behind the counting, and one sum of counters; the key exchange would put 0.5-1.5 GB per
+    step and rank on the links - all of it on one link with two GPUs - and is expected level with it on four only if
+    the all-to-all reaches most of the links' rate), the key exchange of `sharded.py` otherwise.  `mode` or the environment variable NKML_MULTI_GPU ("replicated" / "exchange")
     overrides the choice.  Returns (normaliser, engine, mode)."""
     import os
     from .sharded import HipShardEngine, ShardedNormaliser
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    mode = mode or os.environ.get("NKML_MULTI_GPU") or ("replicated" if world <= 3 and fits(ksize, depth, world, max_bases) else "exchange")
+    mode = mode or os.environ.get("NKML_MULTI_GPU") or ("replicated" if world <= 4 and fits(ksize, depth, world, max_bases) else "exchange")
     if mode == "replicated":
         engine = HipReplicaEngine(ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=profile)
         return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host, root_only=root_only), engine, mode
