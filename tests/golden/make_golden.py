@@ -7,7 +7,7 @@ per-record (kept, high_fwd, high_rev, total_fwd, total_rev) parsed from the refe
 `--debug 2` lines (normalise_kmers_multi_large.c:1682-1692), its final report numbers and the
 md5 of the files it wrote.  No reference source text is stored.
 
-usage: python tools/make_golden.py [case ...]
+usage: python tests/golden/make_golden.py [case ...]
 """
 import hashlib
 import json
@@ -20,7 +20,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "nkml_ref")
 REF_TEST = "/root/reference/test"
 GOLD = os.path.join(ROOT, "tests", "golden")

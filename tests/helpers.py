@@ -208,7 +208,7 @@ def reference_capacity(k, memory_gb):
 def drive_oracle(cfg, model=0, seed=True):
     """Run the oracle the way the reference's main() runs its hot path at --cpu 1: seeding pass over every
     file (normalise_kmers_multi_large.c:2242-2250, 1322-1373), then every file pair / single file in order
-    with one table for the whole run.  Returns per-processed-record arrays like tools/make_golden.py."""
+    with one table for the whole run.  Returns per-processed-record arrays like tests/golden/make_golden.py."""
     k, depth, cov = cfg["k"], cfg["depth"], np.float32(cfg["cov"])
     o = Oracle(k, depth, cfg["canonical"], model, reference_capacity(k, cfg["memory"]) if model else 0)
     fwd = [records(input_path(p), cfg["fastq_in"]) for p in cfg["fwd"]]

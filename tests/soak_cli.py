@@ -2,7 +2,7 @@
 FASTQ/FASTA inputs - paired and single, several files, mates shorter than k, N runs, shared and unrelated reads - through
 oracle/_ref/nkml_ref --cpu 1 and through nkml_amd with the same options, k <= 13 (where the reference's table is
 collision-free by construction); the output files must be the same byte for byte, and the report numbers equal.
-python tools/soak_cli.py [cases] [seed]"""
+python tests/soak_cli.py [cases] [seed]   (not collected by pytest: a long run for the GPU box)"""
 import hashlib, os, re, shutil, subprocess, sys, tempfile
 import numpy as np
 

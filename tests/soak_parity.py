@@ -1,7 +1,7 @@
 """Randomised parity soak on the GPU (a checker run, not a product path): many small random configurations - k, depth,
 canonical, read mix (random, low-complexity, tandem repeats, N runs, poly-G floods), random batch cuts - through the
 C ABI on the partitioned and the atomic counting path, each compared read by read with the CPU oracle.
-python tools/soak_parity.py [cases] [seed]"""
+python tests/soak_parity.py [cases] [seed]   (not collected by pytest: a long run for the GPU box)"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")

@@ -1,5 +1,5 @@
 """Pins the CPU oracle (oracle/nkml_oracle.c) to the reference: the known-answer comment in the reference
-source (normalise_kmers_multi_large.c:56-70) and the vectors under tests/golden/ that tools/make_golden.py
+source (normalise_kmers_multi_large.c:56-70) and the vectors under tests/golden/ that tests/golden/make_golden.py
 captured from the compiled reference on the reference's own test files and on this build's edge inputs."""
 import numpy as np
 import pytest

@@ -7,7 +7,7 @@ per-read path: pairs dropped because a mate is shorter than k, reads of exactly 
 poly-G reads (the same k-mer many times inside one read, so the depth threshold is crossed in the
 middle of a read), reverse-complement mates (canonical mode), tandem repeats, clones that push
 k-mers over the depth, and headers that already end in /1 or /2 (FASTQ->FASTA header rule).
-tools/make_golden.py then runs the compiled reference on them to get the expected outputs.
+tests/golden/make_golden.py then runs the compiled reference on them to get the expected outputs.
 """
 import os
 import random
