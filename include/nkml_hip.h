@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NKML_ABI_VERSION 2
+#define NKML_ABI_VERSION 3
 
 enum {
     NKML_OK = 0,
