@@ -194,8 +194,28 @@ def main():
             torch.cuda.synchronize()
     else:
         from nomalise_kmers_multi_large_amd.replicated import make_multi_gpu_normaliser
-        eng, engine, multi_mode = make_multi_gpu_normaliser(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
-                                                            profile=True, stage_through_host=rehearse, root_only=True)
+
+        def build(mode):
+            """(normaliser, engine, mode) or the exception; a rank must not go on alone, so the outcome is agreed on"""
+            try:
+                made = make_multi_gpu_normaliser(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
+                                                 profile=True, stage_through_host=rehearse, root_only=True, mode=mode)
+            except Exception as e:  # e.g. a context that does not fit: every rank falls back together
+                made = e
+            ok = torch.tensor([0 if isinstance(made, Exception) else 1], dtype=torch.int64, device="cpu" if rehearse else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            return made, bool(ok.item())
+
+        made, ok = build(None)
+        if not ok:  # the mode of choice could not be set up somewhere: the key exchange works for every configuration
+            if isinstance(made, Exception):
+                print("rank %d: %s; falling back to the key exchange" % (rank, made), file=sys.stderr, flush=True)
+            del made
+            torch.cuda.empty_cache()
+            made, ok = build("exchange")
+            if not ok:
+                raise made if isinstance(made, Exception) else RuntimeError("another rank could not set up the key exchange")
+        eng, engine, multi_mode = made
         d_keep_all = torch.zeros((len(dev_steps), world, pps), dtype=torch.uint8, device=dev) if rank == 0 else None
 
         def step(i, last=True):
