@@ -311,7 +311,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",
+            "dtype": "u32" if k <= 16 else "u64",
             "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
             "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d depth=%d coverage=%g, %s" % (
                 n_pairs, k, depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
