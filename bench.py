@@ -70,13 +70,42 @@ def make_dataset(n_pairs, seed, pairs_per_step, first_pair=0):
     return steps
 
 
-def cpu_baseline(sample_seq, sample_off, k, depth, cov, gpu_keep_prefix):
+def _run_reference(ref_bin, tmp, k, depth, cov, extra):
+    """One run of the compiled reference program in `tmp`; returns (its own 'Total runtime' in s or None, wall s, text)."""
+    cmd = [ref_bin, "-f", "s_1.fastq", "-r", "s_2.fastq", "-k", str(k), "-d", str(depth), "-g", repr(cov)] + extra
+    t0 = time.time()
+    res = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False)
+    wall = time.time() - t0
+    text = res.stdout.decode("latin-1")
+    m_rt = re.search(r"Total runtime: ([\d.]+) seconds", text)
+    runtime = float(m_rt.group(1)) if res.returncode == 0 and m_rt else None
+    return runtime, wall, text
+
+
+def usable_cores():
+    """Cores this process may use (the box's share, not the whole machine's count)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var)
+        if v and v.isdigit() and int(v) > 0:
+            n = min(n, int(v))
+    return max(1, n)
+
+
+def cpu_baseline(sample_seq, sample_off, k, depth, cov, gpu_keep_prefix, multi_thread_leg=True, canonical=False):
     """Time the CPU side on a bounded sample of the same workload, on this host's cores.
     Preferred: the compiled reference program (oracle/_ref/nkml_ref, --cpu 1, -m 16 so that its k=15 table is
-    collision-free); otherwise this repo's CPU restatement (oracle/nkml_oracle.so)."""
+    collision-free); otherwise this repo's CPU restatement (oracle/nkml_oracle.so).
+    With the reference present a second, throughput-only run uses --cpu <cores>: it is NOT the same computation
+    (the depth threshold becomes depth / cpus on private per-thread tables, normalise_kmers_multi_large.c:674, and
+    thread 1 re-reads thread 0's chunk, :1247-1261), so only its rate is reported, never its decisions."""
     n_pairs = (len(sample_off) - 1) // 2
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "nkml_ref")
-    out = {"cores": 1, "sample": "first %d pairs of the timed dataset" % n_pairs, "unit": "read-pairs/s"}
+    out = {"cores": 1, "node_cores": os.cpu_count(), "usable_cores": usable_cores(),
+           "sample": "first %d pairs of the timed dataset" % n_pairs, "unit": "read-pairs/s"}
     if os.path.exists(ref_bin) and os.access(ref_bin, os.X_OK):
         tmp = tempfile.mkdtemp(prefix="nkml_bench_")
         try:
@@ -88,25 +117,36 @@ def cpu_baseline(sample_seq, sample_off, k, depth, cov, gpu_keep_prefix):
                     f1.write(h + b"1:N:0:ACGT\n" + seq[2 * i].tobytes() + b"\n+\n" + qual + b"\n")
                     f2.write(h + b"2:N:0:ACGT\n" + seq[2 * i + 1].tobytes() + b"\n+\n" + qual + b"\n")
             mem = ["-m", "16"] if k == 15 else (["-m", "4"] if k == 14 else [])
-            cmd = [ref_bin, "-f", "s_1.fastq", "-r", "s_2.fastq", "-k", str(k), "-d", str(depth), "-g", repr(cov)] + mem
-            t0 = time.time()
-            res = subprocess.run(cmd, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False)
-            wall = time.time() - t0
-            text = res.stdout.decode("latin-1")
-            m_rt = re.search(r"Total runtime: ([\d.]+) seconds", text)
+            canon = ["-c"] if canonical else []
+            runtime, wall, text = _run_reference(ref_bin, tmp, k, depth, cov, mem + canon)
             m_pr = re.search(r"Printed Records: ([\d,]+)", text)
             m_un = re.search(r"Cumulative Max unique kmers in any thread: ([\d,]+)", text)
-            if res.returncode == 0 and m_rt and float(m_rt.group(1)) > 0:
-                runtime = float(m_rt.group(1))
+            if runtime:
                 out.update({"value": n_pairs / runtime, "kind": "reference",
-                            "sample": out["sample"] + "; reference --cpu 1 %s, its own 'Total runtime' %.0f s "
-                                      "(1 s clock, seeding pass and table copy excluded), wall %.1f s" % (" ".join(mem), runtime, wall)})
+                            "value_wall": n_pairs / wall, "wall_s": wall, "reference_clock_s": runtime,
+                            "sample": out["sample"] + "; reference --cpu 1 %s; value = pairs / its own 'Total runtime' (%.0f s on a "
+                                      "1 s clock, seeding pass and table copy excluded), value_wall = pairs / external wall "
+                                      "(%.1f s, everything included)" % (" ".join(mem), runtime, wall)})
                 if m_pr:
                     ref_printed = int(m_pr.group(1).replace(",", ""))
                     out["parity"] = {"pairs": n_pairs, "reference_printed": ref_printed, "gpu_kept": int(gpu_keep_prefix),
-                                     "match": ref_printed == int(gpu_keep_prefix)}
+                                     "match": ref_printed == int(gpu_keep_prefix),
+                                     "note": None if k <= 15 else "k > 16: the reference's table is never collision-free; its "
+                                             "collision artefacts flip a few decisions at this size (rate recorded in "
+                                             "profiles/, tests/refdiff_k25.py)"}
                 if m_un:
                     out["reference_unique_kmers"] = int(m_un.group(1).replace(",", ""))
+                cores = usable_cores()
+                if multi_thread_leg and cores > 1 and depth // cores >= 2:
+                    # default table (1 GiB per thread): -m 16 would be copied once per thread
+                    rt_n, wall_n, _ = _run_reference(ref_bin, tmp, k, depth, cov, ["--cpu", str(cores)] + canon)
+                    out["multi_thread"] = {
+                        "cores": cores, "wall_s": wall_n, "reference_clock_s": rt_n,
+                        "value_wall": n_pairs / wall_n, "value": (n_pairs / rt_n) if rt_n else None, "unit": "read-pairs/s",
+                        "note": "throughput only, semantically different: private per-thread tables with threshold depth/cpus "
+                                "(ref:674), thread 1 re-reads thread 0's chunk (ref:1247-1261), one second of sleep per thread "
+                                "start (ref:1879); the single-threaded seeding pass and the per-thread table copies are "
+                                "inside wall_s but outside the reference's own clock"}
                 return out
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -114,7 +154,7 @@ def cpu_baseline(sample_seq, sample_off, k, depth, cov, gpu_keep_prefix):
     sys.path.insert(0, ROOT)
     from tests.helpers import Oracle
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "nkml_oracle.so"], check=False, stdout=subprocess.DEVNULL)
-    o = Oracle(k, depth)
+    o = Oracle(k, depth, canonical)
     t0 = time.time()
     h, t = o.batch(sample_seq, sample_off.astype(np.uint64))
     dt = time.time() - t0
@@ -137,6 +177,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample-pairs", type=int, default=300000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--canonical", type=int, default=-1, help="1/0; default: on for k > 16 (the k=25 --canonical configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,6 +201,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     k, depth, cov = args.ksize, args.depth, args.coverage
+    canonical = (k > 16) if args.canonical < 0 else bool(args.canonical)
     pps = args.pairs_per_step
     n_pairs = args.steps * pps  # per rank
     # the dataset kept in HBM is bounded (40 M pairs = 12 GB per GPU): a longer run goes round it again, on a table
@@ -175,7 +217,7 @@ def main():
 
     if world == 1:
         from nomalise_kmers_multi_large_amd.normaliser import KmerNormaliser
-        eng = KmerNormaliser(k, depth, cov, canonical=False, device=local_rank, max_batch_reads=2 * pps,
+        eng = KmerNormaliser(k, depth, cov, canonical=canonical, device=local_rank, max_batch_reads=2 * pps,
                              max_batch_bases=2 * pps * READ_LEN, profile=True)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream: library kernels and torch ops stay ordered
         d_high = torch.zeros(2 * pps, dtype=torch.int32, device=dev)
@@ -198,7 +240,7 @@ def main():
         def build(mode):
             """(normaliser, engine, mode) or the exception; a rank must not go on alone, so the outcome is agreed on"""
             try:
-                made = make_multi_gpu_normaliser(k, depth, cov, False, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
+                made = make_multi_gpu_normaliser(k, depth, cov, canonical, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
                                                  profile=True, stage_through_host=rehearse, root_only=True, mode=mode)
             except Exception as e:  # e.g. a context that does not fit: every rank falls back together
                 made = e
@@ -268,38 +310,49 @@ def main():
         unique = int(u.item())
 
     if rank == 0:
-        count_ms = st["count_kernel_ms"]
         launches = max(1, st["count_kernel_launches"])
         occ = st["kmers_counted"]
         partitioned = bool(st.get("partitioned"))
-        # Dominant kernel, timed by the library with HIP events on the launch stream.
-        # Atomic path: one launch counts a chunk of positions and every occurrence is priced as a 16-byte slot read
-        # + write (32 B), the convention of the reference's table layout.
-        # Partitioned path: the table update is spread over a pipeline of streaming kernels, so the 32 B convention
-        # is applied to the whole counting stage (`convention` below) and the dominant kernel, the bucket counter,
-        # is priced with the bytes it has to move by design: one sweep of the 1-byte-per-k-mer table (read + write)
-        # per launch plus a 2-byte key in and a 1-byte flag out per occurrence.
-        kernel = ("k_pt_count_bucket" if partitioned else "k_count_words_direct") if k <= 16 else "k_count_words_hashed"
-        avg_ms = count_ms / launches
-        if partitioned:
-            alg_bytes_per_launch = 2.0 * st["capacity"] + 3.0 * occ / launches
-        else:
-            alg_bytes_per_launch = 32.0 * occ / launches
-        achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        convention = None
+        # `roofline` prices the table update the way the reference's layout defines it: every k-mer occurrence is one
+        # 16-byte slot read + one 16-byte slot write = 32 B (kmer_t, normalise_kmers_multi_large.c:156-161), divided by
+        # the time the device spends on the update, measured with HIP events on the launch stream.
+        #   atomic path      : the update is one kernel per chunk of positions (k_count_words_direct / _hashed);
+        #   partitioned path : the update is a pipeline of streaming kernels (histograms, two partition passes, bucket
+        #                      counting, the flags' way back), so the duration is the whole counting stage of a batch.
+        # `traffic` is the HBM bytes of the same unit from the rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE
+        # doubled as gfx950 needs for wide streaming reads, plus WRITE_SIZE), when a record for this configuration exists.
         if partitioned and st.get("count_stage_ms"):
-            stage_ms = st["count_stage_ms"] / launches
-            conv = 32.0 * occ / launches / (stage_ms * 1e-3) / 1e9
-            convention = {"bytes_per_occurrence": 32, "counting_stage_ms_per_launch": stage_ms, "achieved": conv, "frac": conv / HBM_PEAK_GBS}
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_count_kernel.json")
+            kernel = "counting stage (k_pt_hist_words .. k_pt_ungather)"
+            unit_ms = st["count_stage_ms"] / launches
+        else:
+            kernel = "k_count_words_direct" if k <= 16 else "k_count_words_hashed"
+            unit_ms = st["count_kernel_ms"] / launches
+        occ_per_launch = occ / launches
+        alg_bytes_per_launch = 32.0 * occ_per_launch
+        achieved = alg_bytes_per_launch / (unit_ms * 1e-3) / 1e9 if unit_ms > 0 else 0.0
+        traffic = design = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_counting_stage.json")
         if os.path.exists(pmc_path):
             try:
-                pmc = json.load(open(pmc_path))
-                if pmc.get("ksize") == k and pmc.get("pairs_per_step") == pps and pmc.get("kernel") == kernel:
-                    traffic = pmc.get("hbm_bytes_per_launch")
+                for rec in json.load(open(pmc_path)):
+                    if rec.get("ksize") == k and rec.get("pairs_per_step") == pps and bool(rec.get("partitioned")) == partitioned \
+                            and bool(rec.get("canonical")) == canonical:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        design = rec.get("design_bytes_per_launch")
             except Exception:
                 traffic = None
+        aux = {"avg_launch_ms": unit_ms, "launches": launches, "occurrences_per_launch": occ_per_launch,
+               "algorithmic_bytes_per_occurrence": 32,
+               # what the table update really moves per occurrence here (the reference's 16-byte slot is a 1-byte entry
+               # on the partitioned path, a 4-byte counter on the direct atomic path, a 16-byte slot on the hashed path)
+               "actual_bytes_per_occurrence": (traffic / occ_per_launch) if traffic and occ_per_launch else None,
+               "design_bytes_per_occurrence": (design / occ_per_launch) if design and occ_per_launch else None,
+               "traffic_over_algorithmic": (traffic / alg_bytes_per_launch) if traffic and alg_bytes_per_launch else None}
+        if partitioned:
+            bucket_ms = st["count_kernel_ms"] / launches
+            bucket_bytes = 2.0 * st["capacity"] + 2.125 * occ_per_launch  # table sweep (read + write) + 2-byte key in, flag bit out
+            aux["bucket_kernel"] = {"kernel": "k_pt_count_bucket", "avg_launch_ms": bucket_ms, "design_bytes_per_launch": bucket_bytes,
+                                    "design_GBps": bucket_bytes / (bucket_ms * 1e-3) / 1e9 if bucket_ms > 0 else None}
         result = {
             "metric": "read-pairs/sec at k=%d, 150 bp PE (+ unique-kmers/sec)" % k,
             "value": value,
@@ -313,8 +366,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32" if k <= 16 else "u64",
             "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
-            "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d depth=%d coverage=%g, %s" % (
-                n_pairs, k, depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
+            "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d%s depth=%d coverage=%g, %s" % (
+                n_pairs, k, " --canonical" if canonical else "", depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
                     world, "packed reads all-gathered, every GPU counts its shard" if multi_mode == "replicated" else "RCCL all-to-all of k-mers")),
                 "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d (%s)" % (world, multi_mode),
                 "distinct_steps_of_data": data_steps},
@@ -322,10 +375,9 @@ def main():
             "unique_kmers_per_s": unique / elapsed,
             "kmer_occurrences_per_s": occ * world / elapsed,
             "algorithmic_GBps_whole_path": value * algorithmic_bytes_per_pair(k) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch, "convention": convention},
+            "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "algorithmic_bytes_per_launch": alg_bytes_per_launch}, **aux),
             "table": {"saturated_fraction": st["kmers_saturated"] / max(1, occ), "crossing_kmers": st["crossing_kmers"],
                       "crossing_occurrences": st["crossing_occurrences"]},
         }
@@ -342,7 +394,7 @@ def main():
             eng.decide_device(d_high.data_ptr(), d_total.data_ptr(), nr // 2, True, d_keep.data_ptr())
             sync()
             gpu_kept_prefix = int(d_keep[:sample_pairs].sum(dtype=torch.int64).item())
-            result["cpu_baseline"] = cpu_baseline(sseq, soff, k, depth, cov, gpu_kept_prefix)
+            result["cpu_baseline"] = cpu_baseline(sseq, soff, k, depth, cov, gpu_kept_prefix, canonical=canonical)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"] if result["cpu_baseline"].get("value") else None
         elif world == 1:
             result["cpu_baseline"] = None
