@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NKML_ABI_VERSION 3
+#define NKML_ABI_VERSION 4
 
 enum {
     NKML_OK = 0,
@@ -170,6 +170,16 @@ int nkml_reduce_reads_device(nkml_ctx *ctx, const void *d_keys, const uint8_t *d
  *   unroute_flags : flags returned by the owners, in send order, back to their base positions (others get 0). */
 int nkml_owner_of(uint64_t key, uint32_t n_shards);
 int nkml_route_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
+                           uint32_t *d_send_src, uint64_t *send_counts);
+/*   route_keys_static : nkml_route_keys_device for callers that cannot allocate (code under HIP graph capture, tight
+ *                   serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs,
+ *                   outputs and results as nkml_route_keys_device, but the per-tile shard counts, their scan and the scan's
+ *                   block totals live in a fixed array in device memory (static, about 4 MiB per GPU, held until the
+ *                   process ends) instead of buffers allocated on demand, and the call uses no allocating routine.
+ *                   Limit: ceil(n_keys / 1024) * n_shards <= NKML_ROUTE_STATIC_MAX_ENTRIES, else NKML_E_ARG.  All calls on
+ *                   one GPU share that array: calls that overlap in time on one GPU (two contexts, two streams) race. */
+#define NKML_ROUTE_STATIC_MAX_ENTRIES (1u << 19)
+int nkml_route_keys_static(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
                            uint32_t *d_send_src, uint64_t *send_counts);
 /*   route_reads   : the same partition taken straight from a batch of reads (k-mers recomputed from the packed
  *                   sequence, no key array in between); positions in d_send_src are base positions of the batch. */

@@ -21,7 +21,7 @@ EXPORTS = [
     "nkml_abi_version", "nkml_strerror", "nkml_last_error", "nkml_create", "nkml_destroy", "nkml_reset", "nkml_host_staging", "nkml_wait_staged",
     "nkml_set_stream", "nkml_synchronize", "nkml_get_stats", "nkml_submit", "nkml_collect", "nkml_process_device",
     "nkml_seed", "nkml_keep_pair", "nkml_keep_single", "nkml_decide_device", "nkml_key_bytes", "nkml_kmerise_device",
-    "nkml_count_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_reads_device",
+    "nkml_count_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_keys_static", "nkml_route_reads_device",
     "nkml_unroute_flags_device", "nkml_set_shard", "nkml_shard_of", "nkml_pack_device", "nkml_process_packed_device",
 ]
 
@@ -97,6 +97,7 @@ def load_library():
     lib.nkml_dump_table.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64)]
     lib.nkml_owner_of.argtypes = [u64, u32]
     lib.nkml_route_keys_device.argtypes = [vp, vp, u64, u32, vp, vp, ctypes.POINTER(u64)]
+    lib.nkml_route_keys_static.argtypes = [vp, vp, u64, u32, vp, vp, ctypes.POINTER(u64)]
     lib.nkml_route_reads_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, ctypes.POINTER(u64)]
     lib.nkml_unroute_flags_device.argtypes = [vp, vp, vp, u64, vp, u64]
     lib.nkml_set_shard.argtypes = [vp, u32, u32]

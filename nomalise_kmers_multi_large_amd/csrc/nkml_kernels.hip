@@ -1064,6 +1064,75 @@ __global__ void __launch_bounds__(256) k_unroute_flags(const uint8_t *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_sent; i += stride) flags[send_src[i]] = recv_flags[i];
 }
 
+// Exclusive scan of a u32 array in three small launches (block sums, scan of the sums, per-block scan + base): used
+// where the library must not call anything that might allocate (nkml_route_keys_static).  n <= SCAN_BLOCK * 2048.
+constexpr int SCAN_BLOCK = 1024; // entries per workgroup of 256 lanes
+
+__global__ void __launch_bounds__(256) k_scan_block_sums(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t red[4];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (base + j < n) v += in[base + j];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup of 1024 lanes, two sums per lane: sums[i] becomes the total of the blocks before block i
+__global__ void __launch_bounds__(1024) k_scan_sums(uint32_t *__restrict__ sums, uint32_t n_blocks)
+{
+    __shared__ uint32_t wtot[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t i0 = threadIdx.x * 2;
+    const uint32_t a = i0 < n_blocks ? sums[i0] : 0u, b = i0 + 1 < n_blocks ? sums[i0 + 1] : 0u;
+    uint32_t incl = a + b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wv; w++) before += wtot[w];
+    const uint32_t excl = before + incl - (a + b);
+    if (i0 < n_blocks) sums[i0] = excl;
+    if (i0 + 1 < n_blocks) sums[i0 + 1] = excl + a;
+}
+
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ in, uint32_t n, const uint32_t *__restrict__ sums,
+                                                    uint32_t *__restrict__ out)
+{
+    __shared__ uint32_t wtot[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * 4;
+    uint32_t v[4], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        v[j] = base + j < n ? in[base + j] : 0u;
+        mine += v[j];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(incl, o);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t run = sums[blockIdx.x] + incl - mine;
+    for (int w = 0; w < wv; w++) run += wtot[w];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+}
+
 #include "nkml_partition.inc"
 
 // table dump helpers
@@ -1097,6 +1166,15 @@ __global__ void __launch_bounds__(256) k_dump_hashed(const Slot *__restrict__ sl
 // ======================================================================================================
 // Host side: context and C ABI
 // ======================================================================================================
+// Scratch of nkml_route_keys_static, the one entry point that never allocates: per-tile shard counts, their scan and
+// the scan's block sums live in this fixed array instead of buffers the library allocates on demand.  Every GPU the
+// library runs on holds its own copy (4 MiB + 8 KiB) until the process ends; the host reaches it only through the
+// per-device address taken once with hipGetSymbolAddress (the array's name is not a device address in host code).
+#define NKML_ROUTE_STATIC_ENTRIES NKML_ROUTE_STATIC_MAX_ENTRIES /* (tiles of 1024 keys) x shards, e.g. 128 Mi keys for 4 shards */
+static __device__ __align__(256) uint32_t scratch[2 * (NKML_ROUTE_STATIC_ENTRIES + 64) + 2048];
+constexpr int MAX_DEVICES = 64;
+static uint32_t *g_scratch_ptr[MAX_DEVICES]; // device address of `scratch` on each device, null until first asked for
+
 struct nkml_ctx {
     nkml_config cfg;
     int key_bytes;          // 4 for k <= 16, else 8
@@ -1149,6 +1227,7 @@ struct nkml_ctx {
     uint64_t route_entries;
     void *d_route_tmp;
     size_t route_tmp_bytes;
+    uint32_t *h_route_starts; // pinned: shard start offsets of the last routing call (65 entries)
 
     Counters *d_ctr;
     Counters *h_ctr;        // pinned
@@ -1726,6 +1805,13 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     CREATE_HIP(hipMalloc(&c->d_ctr, sizeof(Counters)));
     CREATE_HIP(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
     memset(c->h_ctr, 0, sizeof(Counters));
+    CREATE_HIP(hipHostMalloc(&c->h_route_starts, 72 * sizeof(uint32_t), hipHostMallocDefault));
+    if (cfg->device < MAX_DEVICES && !g_scratch_ptr[cfg->device]) {
+        // this device's copy of the static scratch array (the device is current: hipSetDevice above)
+        void *p = nullptr;
+        CREATE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[cfg->device] = static_cast<uint32_t *>(p);
+    }
     CREATE_CHK(alloc_table(c));
     CREATE_HIP(hipMalloc(&c->d_seq, npos + 64));
     CREATE_HIP(hipMalloc(&c->d_offsets, ((uint64_t)cfg->max_batch_reads + 1) * sizeof(uint64_t)));
@@ -1772,6 +1858,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
     hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
+    if (c->h_route_starts) hipHostFree(c->h_route_starts);
     if (c->h_seq) hipHostFree(c->h_seq);
     if (c->h_offsets) hipHostFree(c->h_offsets);
     if (c->h_high) hipHostFree(c->h_high);
@@ -2069,6 +2156,50 @@ int nkml_owner_of(uint64_t key, uint32_t n_shards) { return n_shards ? (int)owne
 
 // Stable partition of one batch's keys by owning shard.  d_keys != nullptr: from a key array; else from the packed
 // words the context prepared (n_bases of them).
+// hist / off: (tiles x shards + 1) entries each.  sums == nullptr: the scan is rocPRIM's, with the context's temporary
+// storage; else the three-launch scan above with `sums` for its block totals (nothing that could allocate).
+static int route_run(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t n_bases, uint32_t n_shards, void *d_send_keys,
+                     uint32_t *d_send_src, uint64_t *send_counts, uint32_t *hist, uint32_t *off, uint32_t *sums)
+{
+    const uint64_t n_waves = (n_keys + ROUTE_TILE - 1) / ROUTE_TILE;
+    const uint64_t entries = n_waves * n_shards;
+    const uint32_t grid = blocks_for(n_waves, 4);
+    HIPCHK(c, hipMemsetAsync(hist + entries, 0, sizeof(uint32_t), c->stream)); // one extra entry: the scan's last output = total
+    RouteSource src = {d_keys, c->d_packed, c->d_startbits, n_bases, c->cfg.ksize};
+    const int mode = d_keys ? 0 : c->cfg.canonical ? 2 : 1;
+#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, hist)
+#define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, off, \
+                                                   (KEY *)d_send_keys, d_send_src)
+#define ROUTE_DISPATCH(WHAT)                                                                                      \
+    do {                                                                                                          \
+        if (c->key_bytes == 4) { if (mode == 0) WHAT(uint32_t, 0); else if (mode == 1) WHAT(uint32_t, 1); else WHAT(uint32_t, 2); } \
+        else { if (mode == 0) WHAT(unsigned long long, 0); else if (mode == 1) WHAT(unsigned long long, 1); else WHAT(unsigned long long, 2); } \
+    } while (0)
+    ROUTE_DISPATCH(ROUTE_COUNT);
+    HIPCHK(c, hipGetLastError());
+    if (sums) {
+        const uint32_t n = (uint32_t)(entries + 1), nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(k_scan_block_sums, nb, 256, 0, c->stream, hist, n, sums);
+        hipLaunchKernelGGL(k_scan_sums, 1, 1024, 0, c->stream, sums, nb);
+        hipLaunchKernelGGL(k_scan_apply, nb, 256, 0, c->stream, hist, n, sums, off);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        size_t tmp = c->route_tmp_bytes;
+        HIPCHK(c, rocprim::exclusive_scan(c->d_route_tmp, tmp, hist, off, 0u, (size_t)(entries + 1), rocprim::plus<uint32_t>(), c->stream));
+    }
+    ROUTE_DISPATCH(ROUTE_SCATTER);
+#undef ROUTE_DISPATCH
+#undef ROUTE_SCATTER
+#undef ROUTE_COUNT
+    HIPCHK(c, hipGetLastError());
+    // per-shard totals = differences of the shard start offsets (through pinned memory: no staging by the runtime)
+    for (uint32_t s = 0; s <= n_shards; s++)
+        HIPCHK(c, hipMemcpyAsync(&c->h_route_starts[s], off + (uint64_t)s * n_waves, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = c->h_route_starts[s + 1] - c->h_route_starts[s];
+    return NKML_OK;
+}
+
 static int route_common(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t n_bases, uint32_t n_shards, void *d_send_keys,
                         uint32_t *d_send_src, uint64_t *send_counts)
 {
@@ -2090,34 +2221,7 @@ static int route_common(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64
         c->route_tmp_bytes = tmp ? tmp : 256;
         HIPCHK(c, hipMalloc(&c->d_route_tmp, c->route_tmp_bytes));
     }
-    const uint32_t grid = blocks_for(n_waves, 4);
-    HIPCHK(c, hipMemsetAsync(c->d_route_hist + entries, 0, sizeof(uint32_t), c->stream)); // one extra entry: the scan's last output = total
-    RouteSource src = {d_keys, c->d_packed, c->d_startbits, n_bases, c->cfg.ksize};
-    const int mode = d_keys ? 0 : c->cfg.canonical ? 2 : 1;
-#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, c->d_route_hist)
-#define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, c->d_route_off, \
-                                                   (KEY *)d_send_keys, d_send_src)
-#define ROUTE_DISPATCH(WHAT)                                                                                      \
-    do {                                                                                                          \
-        if (c->key_bytes == 4) { if (mode == 0) WHAT(uint32_t, 0); else if (mode == 1) WHAT(uint32_t, 1); else WHAT(uint32_t, 2); } \
-        else { if (mode == 0) WHAT(unsigned long long, 0); else if (mode == 1) WHAT(unsigned long long, 1); else WHAT(unsigned long long, 2); } \
-    } while (0)
-    ROUTE_DISPATCH(ROUTE_COUNT);
-    HIPCHK(c, hipGetLastError());
-    size_t tmp = c->route_tmp_bytes;
-    HIPCHK(c, rocprim::exclusive_scan(c->d_route_tmp, tmp, c->d_route_hist, c->d_route_off, 0u, (size_t)(entries + 1), rocprim::plus<uint32_t>(), c->stream));
-    ROUTE_DISPATCH(ROUTE_SCATTER);
-#undef ROUTE_DISPATCH
-#undef ROUTE_SCATTER
-#undef ROUTE_COUNT
-    HIPCHK(c, hipGetLastError());
-    // per-shard totals = differences of the shard start offsets
-    uint32_t starts[65];
-    for (uint32_t s = 0; s <= n_shards; s++)
-        HIPCHK(c, hipMemcpyAsync(&starts[s], c->d_route_off + (uint64_t)s * n_waves, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = starts[s + 1] - starts[s];
-    return NKML_OK;
+    return route_run(c, d_keys, n_keys, n_bases, n_shards, d_send_keys, d_send_src, send_counts, c->d_route_hist, c->d_route_off, nullptr);
 }
 
 int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
@@ -2126,6 +2230,27 @@ int nkml_route_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
     if (!c || !d_keys || !d_send_keys || !d_send_src || !send_counts || n_shards == 0 || n_shards > 64) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     return route_common(c, d_keys, n_keys, 0, n_shards, d_send_keys, d_send_src, send_counts);
+}
+
+int nkml_route_keys_static(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
+                           uint32_t *d_send_src, uint64_t *send_counts)
+{
+    if (!c || !d_keys || !d_send_keys || !d_send_src || !send_counts || n_shards == 0 || n_shards > 64) return NKML_E_ARG;
+    if (n_keys >= (1ull << 32)) return fail(c, NKML_E_ARG, "too many keys for 32-bit source positions");
+    const uint64_t n_waves = (n_keys + ROUTE_TILE - 1) / ROUTE_TILE, entries = n_waves * n_shards;
+    if (entries > NKML_ROUTE_STATIC_ENTRIES)
+        return fail(c, NKML_E_ARG, "nkml_route_keys_static: %llu keys for %u shards need %llu scratch entries, the fixed scratch holds %u "
+                                   "(use nkml_route_keys_device, which allocates)",
+                    (unsigned long long)n_keys, n_shards, (unsigned long long)entries, NKML_ROUTE_STATIC_ENTRIES);
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    uint32_t *sp = c->cfg.device < MAX_DEVICES ? g_scratch_ptr[c->cfg.device] : nullptr;
+    if (!sp) return fail(c, NKML_E_STATE, "no static scratch on device %d", c->cfg.device);
+    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = 0;
+    if (n_keys == 0) return NKML_OK;
+    // every entry the kernels read is written first by this call (counts: one per (tile, shard); the extra entry and
+    // the block sums: below), so what the last call left in the array does not matter
+    uint32_t *hist = sp, *off = sp + (NKML_ROUTE_STATIC_ENTRIES + 64), *sums = sp + 2 * (NKML_ROUTE_STATIC_ENTRIES + 64);
+    return route_run(c, d_keys, n_keys, 0, n_shards, d_send_keys, d_send_src, send_counts, hist, off, sums);
 }
 
 int nkml_route_reads_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t n_shards,

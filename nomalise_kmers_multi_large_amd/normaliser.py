@@ -196,6 +196,12 @@ class KmerNormaliser:
         self._chk(self.lib.nkml_route_keys_device(self.h, d_keys, n_keys, n_shards, d_send_keys, d_send_src, counts))
         return [int(x) for x in counts]
 
+    def route_keys_static(self, d_keys, n_keys, n_shards, d_send_keys, d_send_src):
+        """nkml_route_keys_device without any allocation (fixed scratch in device memory; see include/nkml_hip.h)"""
+        counts = (ctypes.c_uint64 * n_shards)()
+        self._chk(self.lib.nkml_route_keys_static(self.h, d_keys, n_keys, n_shards, d_send_keys, d_send_src, counts))
+        return [int(x) for x in counts]
+
     def route_reads_device(self, d_seq, d_offsets, n_reads, n_bases, n_shards, d_send_keys, d_send_src):
         counts = (ctypes.c_uint64 * n_shards)()
         self._chk(self.lib.nkml_route_reads_device(self.h, d_seq, d_offsets, n_reads, n_bases, n_shards, d_send_keys, d_send_src, counts))
