@@ -69,8 +69,8 @@ typedef struct nkml_config {
                                   a second 4^k-entry counter array */
 #define NKML_F_COUNT_ATOMIC 4u /* count with atomics on the table even where the partitioned path would be chosen */
 #define NKML_F_COUNT_PARTITIONED 8u /* count by radix-partitioning each batch's k-mers into 2^14-code buckets that are
-                                  counted in LDS against a 1-byte-per-k-mer table, wherever that path can run
-                                  (k <= 15, depth <= 127, no NKML_F_EXACT_COUNTS).  With neither flag the library
+                                  counted in LDS against a table of one byte per k-mer (two for depth > 127), wherever
+                                  that path can run (k <= 15, depth <= 16383, no NKML_F_EXACT_COUNTS).  With neither flag the library
                                   chooses: partitioned at k = 15 and, for batches up to about 2 M pairs of 150 bases,
                                   at k = 14; atomics otherwise; the environment variable NKML_PARTITIONED=0/1
                                   overrides that choice.  Results are identical either way. */

@@ -1188,9 +1188,10 @@ struct nkml_ctx {
     uint32_t *sat;          // direct: saturation bitmap
     uint32_t *extra;        // direct, NKML_F_EXACT_COUNTS: occurrences counted after saturation
     uint32_t *filter;       // crossing filter (both table kinds)
-    // partitioned counting (k <= 15, depth <= 127): one byte per k-mer and the buffers of the two radix passes
+    // partitioned counting (k <= 15): one or two bytes per k-mer and the buffers of the two radix passes
     bool partitioned;
-    uint8_t *pt_table;
+    bool pt_wide;           // two-byte table entries (depth > 127)
+    void *pt_table;
     uint32_t *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
     uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
@@ -1283,12 +1284,18 @@ uint64_t default_hashed_capacity(int memory_gb)
     return cap;
 }
 
+// bytes of the partitioned path's table: one entry per k-mer, at least one bucket
+uint64_t pt_table_bytes(const nkml_ctx *c)
+{
+    const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+    return entries * (c->pt_wide ? 2 : 1);
+}
+
 int alloc_table(nkml_ctx *c)
 {
     if (c->partitioned) {
         c->capacity = 1ull << (2 * c->cfg.ksize);
-        const uint64_t bytes = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
-        HIPCHK(c, hipMalloc(&c->pt_table, bytes));
+        HIPCHK(c, hipMalloc(&c->pt_table, pt_table_bytes(c)));
         const uint64_t npos = c->max_words * 16;
         c->pt_tiles_a = (npos + PT_TILE - 1) / PT_TILE;
         c->pt_tiles_b = c->pt_tiles_a + 256 + 1;
@@ -1309,7 +1316,8 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_tally, ((c->capacity >> PT_LOWBITS) + 1) * sizeof(uint4)));
         HIPCHK(c, hipMalloc(&c->pt_totals, 256 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_chunks, 256 * ((c->pt_tiles_b + 1 + PT_CH - 1) / PT_CH + 1) * sizeof(uint32_t)));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         return NKML_OK;
     }
     if (c->direct) {
@@ -1340,8 +1348,7 @@ hipError_t zero_device(void *p, uint64_t bytes, hipStream_t stream)
 int clear_table(nkml_ctx *c)
 {
     if (c->partitioned) {
-        const uint64_t bytes = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
-        HIPCHK(c, zero_device(c->pt_table, bytes, c->stream));
+        HIPCHK(c, zero_device(c->pt_table, pt_table_bytes(c), c->stream));
     } else if (c->direct) {
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, zero_device(c->counts, c->capacity * sizeof(uint32_t), c->stream));
@@ -1645,14 +1652,22 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
                        c->pt_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
+    const uint32_t depth = (uint32_t)c->cfg.depth;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_pt_count_bucket, (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
-                       (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
+    if (c->pt_wide)
+        hipLaunchKernelGGL((k_pt_count_bucket<uint16_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
+    else
+        hipLaunchKernelGGL((k_pt_count_bucket<uint8_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
-
-    hipLaunchKernelGGL(k_pt_count_bucket_big, (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, tb, c->pt_pad, c->pt_table,
-                       (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+    if (c->pt_wide)
+        hipLaunchKernelGGL((k_pt_count_bucket_big<uint16_t>), (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+    else
+        hipLaunchKernelGGL((k_pt_count_bucket_big<uint8_t>), (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
         hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
@@ -1755,11 +1770,12 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     c->cfg = *cfg;
     c->direct = cfg->ksize <= 16;
     {
-        // the partitioned path needs 30-bit codes, 7-bit saturating counts and no exact counts past depth; it pays
+        // the partitioned path needs 30-bit codes, saturating counts of 7 or 15 bits and no exact counts past depth; it pays
         // where a batch spreads over many 2^14-code buckets (4^15 / 2^14 = 65536 at k = 15)
         // (and batches whose padded first-pass output still fits 32-bit positions)
-        const bool can = cfg->ksize <= 15 && cfg->depth <= 127 && !(cfg->flags & NKML_F_EXACT_COUNTS) &&
+        const bool can = cfg->ksize <= 15 && cfg->depth <= (int32_t)PT_MAX_DEPTH_WIDE && !(cfg->flags & NKML_F_EXACT_COUNTS) &&
                          cfg->max_batch_bases < (1ull << 32) - (4ull << 20);
+        c->pt_wide = cfg->depth > 127;
         const char *env = getenv("NKML_PARTITIONED");
         // chosen by default where a full batch leaves the buckets well inside the fast bucket kernel's reach
         // (fewer than 65535 keys each): k = 15 always, k = 14 up to about 2 M pairs of 150 bases per batch
@@ -1909,7 +1925,7 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     memset(out, 0, sizeof *out);
     out->unique_kmers = c->h_ctr->unique;
     out->capacity = c->capacity;
-    out->table_bytes = c->partitioned ? c->capacity : c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
+    out->table_bytes = c->partitioned ? c->capacity * (c->pt_wide ? 2 : 1) : c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
     out->kmers_counted = c->h_ctr->counted;
     out->kmers_saturated = c->h_ctr->saturated;
     out->crossing_kmers = c->h_ctr->total_cross;
@@ -2293,7 +2309,12 @@ int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max
     HIPCHK(c, hipMalloc(&d_n, sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
     if (c->partitioned)
-        hipLaunchKernelGGL(k_pt_dump, GRID_PERSIST, 256, 0, c->stream, c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
+    {
+        if (c->pt_wide)
+            hipLaunchKernelGGL((k_pt_dump<uint16_t>), GRID_PERSIST, 256, 0, c->stream, (const uint16_t *)c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
+        else
+            hipLaunchKernelGGL((k_pt_dump<uint8_t>), GRID_PERSIST, 256, 0, c->stream, (const uint8_t *)c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
+    }
     else if (c->direct)
         hipLaunchKernelGGL(k_dump_direct, GRID_PERSIST, 256, 0, c->stream, c->counts, c->extra, c->capacity, d_codes, d_cnts, max_entries, d_n);
     else

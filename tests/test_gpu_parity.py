@@ -291,7 +291,7 @@ class partitioned_mode:
 
 
 @pytest.mark.parametrize("k,depth,canonical", [(5, 2, False), (7, 5, True), (9, 100, True), (9, 127, False), (13, 3, False), (15, 3, False),
-                                               (15, 100, True)])
+                                               (15, 100, True), (9, 128, False), (7, 255, True), (5, 1000, False), (13, 200, False)])
 def test_partitioned_random_reads(nk, oracle_lib, k, depth, canonical):
     rng = np.random.default_rng(4000 + k * 7 + depth)
     reads = random_reads(rng, 600, k, 4 * k + 40, b"AC") + random_reads(rng, 600, k, 200, b"ACGT", 0.01) \
@@ -306,7 +306,26 @@ def test_partitioned_random_reads(nk, oracle_lib, k, depth, canonical):
         assert g.unique_kmers == o.unique
         st = g.stats()
         assert st["kmers_counted"] == int(total.sum())
-        assert st["table_bytes"] == st["capacity"]  # the one-byte-per-k-mer table: the partitioned path is the one that ran
+        # one byte per k-mer up to depth 127, two beyond: the partitioned path is the one that ran
+        assert st["partitioned"] == 1 and st["table_bytes"] == st["capacity"] * (1 if depth <= 127 else 2)
+
+
+@pytest.mark.parametrize("n_reads,per_batch", [(300, 400), (700, 400), (1200, 2000)])
+def test_partitioned_largest_depth(nk, oracle_lib, n_reads, per_batch):
+    """depth 16383, the largest the partitioned path takes (two-byte table entries): two k-mers cross it in the middle of
+    a batch; with 1200 reads in one batch their bucket holds more than 65535 keys (the other bucket kernel)."""
+    k, depth = 5, 16383
+    rng = np.random.default_rng(n_reads)
+    reads = [b"AC" * 75] * n_reads + random_reads(rng, 50, k, 120, b"ACGT")
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    o = oracle_lib(k, depth)
+    want = [o.read(r) for r in reads]
+    with partitioned_mode(True), nk.KmerNormaliser(k, depth, 0.9, max_batch_reads=per_batch, max_batch_bases=per_batch * 150) as g:
+        ok, high, total = g.process_sequence_single(reads)
+        np.testing.assert_array_equal(high, [w[1] for w in want])
+        np.testing.assert_array_equal(total, [w[2] for w in want])
+        assert g.unique_kmers == o.unique and g.stats()["partitioned"] == 1
+        assert int(high.sum()) > 0
 
 
 @pytest.mark.parametrize("on", [False, True])
