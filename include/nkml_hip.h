@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NKML_ABI_VERSION 4
+#define NKML_ABI_VERSION 5
 
 enum {
     NKML_OK = 0,
@@ -112,10 +112,14 @@ int nkml_get_stats(nkml_ctx *ctx, nkml_stats *out);
 
 /* Host-buffer path (what the command-line host uses): reads concatenated in `seq`, read i occupies
  * [offsets[i], offsets[i+1]); mates of a pair are consecutive reads (forward first, ref:1559-1563).
- * submit stages the batch with hipMemcpyAsync and enqueues the kernels (on the partitioned path it returns without
- * waiting for the device, so the caller can work while the batch is counted; the atomic path waits once inside
- * submit); collect waits, reports a bad base (NKML_E_BADBASE) if the batch held one, and returns the per-read
- * counters in submission order.  Batch form of process_sequence_pair/_single (ref:1551, 1539). */
+ * submit stages the batch with hipMemcpyAsync and enqueues the kernels.  On the partitioned path it returns without
+ * waiting for the device, so the caller can work while the batch is counted, and collect reports a bad base
+ * (NKML_E_BADBASE) if the batch held one.  On the atomic path submit waits once inside (for the number of occurrences to
+ * rank) and returns NKML_E_BADBASE itself; nothing is pending then and collect must not be called for that batch.
+ * collect waits and returns the per-read counters in submission order.
+ * Memory of the hashed table (k > 16): it starts at memory_gb GiB and doubles whenever a counting pass (chunk_bases
+ * positions) could take it beyond 80 % full; during a doubling the old and the new table coexist, and the next table is
+ * allocated ahead of time once the current one is 40 % full, so the path holds up to 3x the current table's bytes.  Batch form of process_sequence_pair/_single (ref:1551, 1539). */
 int nkml_submit(nkml_ctx *ctx, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
 int nkml_collect(nkml_ctx *ctx, int32_t *high, int32_t *total);
 /* The context's own pinned staging area (max_batch_bases bytes, max_batch_reads + 1 offsets): a caller that
@@ -160,6 +164,9 @@ int nkml_kmerise_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_o
 int nkml_count_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint8_t *d_flags);
 int nkml_reduce_reads_device(nkml_ctx *ctx, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets,
                              uint32_t n_reads, int32_t *d_high, int32_t *d_total);
+/*   seed_keys : the seeding insert of nkml_seed (sequence_to_hash_zero, ref:1501-1537) for keys that are already made: every
+ *               non-zero key enters the table with count 0.  n_keys must be a multiple of 16.  Synchronous. */
+int nkml_seed_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys);
 
 /* Sharding of the table over several devices (one context per device, each holding the counts of the keys it
  * owns).  The reference never merges its per-thread tables (ref:2421); this exchange step is new.
@@ -207,6 +214,30 @@ int nkml_shard_of(uint64_t key, uint32_t n_shards);
 int nkml_pack_device(nkml_ctx *ctx, const uint8_t *d_seq, uint64_t n_bases, uint32_t *d_words);
 int nkml_process_packed_device(nkml_ctx *ctx, const uint32_t *d_words, const uint64_t *d_offsets, uint32_t n_reads,
                                uint64_t n_bases, int32_t *d_high, int32_t *d_total);
+
+/* One table over several GPUs, driven from one process (what the command-line host uses when it is given several
+ * devices).  The reference has no counterpart: its threads keep private tables and never merge them (ref:2421).  The
+ * table is sharded by k-mer (nkml_owner_of); every batch is cut into one contiguous slice of reads per device, the
+ * k-mers travel to their owners (RCCL send/receive over xGMI when every shard has a GPU of its own, device-to-device
+ * copies when shards share a GPU - NKML_TRANSPORT=copy|rccl overrides), are counted there, and the flags travel back;
+ * the per-read counters are those of one table reading the batch in stream order, whatever the number of devices.
+ *   create   : devices[i] = HIP ordinal of shard i (an ordinal may repeat: shards then share that GPU, which is how the
+ *              path is exercised on a one-GPU machine); cfg->device is ignored, cfg->max_batch_* are for the whole batch.
+ *              On failure *out may still be set, for nkml_multi_last_error; destroy it.
+ *   the rest : as the single-device functions of the same name (host buffers, submit / collect in pairs). */
+typedef struct nkml_multi nkml_multi;
+int nkml_multi_create(const nkml_config *cfg, const int32_t *devices, uint32_t n_devices, nkml_multi **out);
+void nkml_multi_destroy(nkml_multi *m);
+const char *nkml_multi_last_error(const nkml_multi *m);
+uint32_t nkml_multi_device_count(const nkml_multi *m);
+int nkml_multi_reset(nkml_multi *m);
+int nkml_multi_host_staging(nkml_multi *m, uint8_t **seq, uint64_t **offsets);
+int nkml_multi_wait_staged(nkml_multi *m);
+int nkml_multi_submit(nkml_multi *m, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
+int nkml_multi_collect(nkml_multi *m, int32_t *high, int32_t *total);
+int nkml_multi_seed(nkml_multi *m, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads);
+int nkml_multi_get_stats(nkml_multi *m, nkml_stats *out);
+int nkml_multi_dump_table(nkml_multi *m, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries);
 
 #define NKML_FLAG_NONE 0u /* no k-mer at this position */
 #define NKML_FLAG_HIGH 1u /* occurrence whose stream-order count is >= depth */

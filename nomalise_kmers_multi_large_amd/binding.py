@@ -21,8 +21,11 @@ EXPORTS = [
     "nkml_abi_version", "nkml_strerror", "nkml_last_error", "nkml_create", "nkml_destroy", "nkml_reset", "nkml_host_staging", "nkml_wait_staged",
     "nkml_set_stream", "nkml_synchronize", "nkml_get_stats", "nkml_submit", "nkml_collect", "nkml_process_device",
     "nkml_seed", "nkml_keep_pair", "nkml_keep_single", "nkml_decide_device", "nkml_key_bytes", "nkml_kmerise_device",
-    "nkml_count_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_keys_static", "nkml_route_reads_device",
+    "nkml_count_keys_device", "nkml_seed_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_keys_static", "nkml_route_reads_device",
     "nkml_unroute_flags_device", "nkml_set_shard", "nkml_shard_of", "nkml_pack_device", "nkml_process_packed_device",
+    "nkml_multi_create", "nkml_multi_destroy", "nkml_multi_last_error", "nkml_multi_device_count", "nkml_multi_reset",
+    "nkml_multi_host_staging", "nkml_multi_wait_staged", "nkml_multi_submit", "nkml_multi_collect", "nkml_multi_seed",
+    "nkml_multi_get_stats", "nkml_multi_dump_table",
 ]
 
 
@@ -93,6 +96,7 @@ def load_library():
     lib.nkml_key_bytes.argtypes = [vp]
     lib.nkml_kmerise_device.argtypes = [vp, vp, vp, u32, u64, vp]
     lib.nkml_count_keys_device.argtypes = [vp, vp, u64, vp]
+    lib.nkml_seed_keys_device.argtypes = [vp, vp, u64]
     lib.nkml_reduce_reads_device.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.nkml_dump_table.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64)]
     lib.nkml_owner_of.argtypes = [u64, u32]
@@ -104,5 +108,20 @@ def load_library():
     lib.nkml_shard_of.argtypes = [u64, u32]
     lib.nkml_pack_device.argtypes = [vp, vp, u64, vp]
     lib.nkml_process_packed_device.argtypes = [vp, vp, vp, u32, u64, vp, vp]
+    lib.nkml_multi_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(i32), u32, ctypes.POINTER(vp)]
+    lib.nkml_multi_destroy.argtypes = [vp]
+    lib.nkml_multi_destroy.restype = None
+    lib.nkml_multi_last_error.argtypes = [vp]
+    lib.nkml_multi_last_error.restype = ctypes.c_char_p
+    lib.nkml_multi_device_count.argtypes = [vp]
+    lib.nkml_multi_device_count.restype = u32
+    lib.nkml_multi_reset.argtypes = [vp]
+    lib.nkml_multi_host_staging.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    lib.nkml_multi_wait_staged.argtypes = [vp]
+    lib.nkml_multi_submit.argtypes = [vp, vp, vp, u32]
+    lib.nkml_multi_collect.argtypes = [vp, vp, vp]
+    lib.nkml_multi_seed.argtypes = [vp, vp, vp, u32]
+    lib.nkml_multi_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    lib.nkml_multi_dump_table.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64)]
     _LIB = lib
     return lib

@@ -779,6 +779,28 @@ __global__ void __launch_bounds__(256) k_seed_words(const uint32_t *__restrict__
     flush_tallies(uniq, 0, 0, ctr);
 }
 
+// the same insert for keys that are already made (the owner side of the multi-device exchange)
+template <typename KEY, bool DIRECT>
+__global__ void __launch_bounds__(256) k_seed_keys(const KEY *__restrict__ keys, uint64_t n, uint32_t *__restrict__ counts, Slot *__restrict__ slots,
+                                                   uint64_t cap_mask, Counters *ctr)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint32_t uniq = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const KEY key = keys[i];
+        if (!key) continue;
+        if (DIRECT) {
+            if (atomicOr(&counts[key], SEEDED_BIT) == 0) uniq++;
+        } else {
+            bool inserted; uint32_t state;
+            const uint64_t h = find_or_insert(slots, cap_mask, (uint64_t)key, inserted, state);
+            if (h == ~0ull) atomicAdd(&ctr->probe_overflow, 1u);
+            else if (inserted) uniq++;
+        }
+    }
+    flush_tallies(uniq, 0, 0, ctr);
+}
+
 // K4a on word flags: occurrences marked LOW whose k-mer crossed in this pass -> (id << posbits) | position.
 template <bool CANON, bool DIRECT>
 __global__ void __launch_bounds__(256) k_collect_words(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits,
@@ -1203,6 +1225,9 @@ struct nkml_ctx {
     bool pt_timing_pending;
     double pt_stage_ms;
     Slot *slots;            // hashed
+    Slot *spare_slots;      // hashed: the next table, allocated ahead of the batch that will need it (or null)
+    uint64_t spare_capacity;
+    uint64_t used_bound;    // hashed: upper bound on the stored keys (last fetched count + positions enqueued since)
     uint64_t capacity;      // slots / counters
     uint64_t resizes;
 
@@ -1373,28 +1398,6 @@ int fetch_counters(nkml_ctx *c)
     return NKML_OK;
 }
 
-// Grow the hashed table until `incoming` more distinct keys still leave it under 80 % full
-// (TABLE_LOAD_FACTOR, normalise_kmers_multi_large.c:143, 933).
-int ensure_capacity(nkml_ctx *c, uint64_t incoming)
-{
-    if (c->direct) return NKML_OK;
-    uint64_t used = c->h_ctr->unique;
-    while ((double)(used + incoming) >= (double)c->capacity * 0.8) {
-        uint64_t ncap = c->capacity * 2;
-        Slot *ns = nullptr;
-        HIPCHK(c, hipMalloc(&ns, ncap * sizeof(Slot)));
-        HIPCHK(c, zero_device(ns, ncap * sizeof(Slot), c->stream));
-        hipLaunchKernelGGL(k_rehash, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, ns, ncap - 1, c->d_ctr);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipFree(c->slots));
-        c->slots = ns;
-        c->capacity = ncap;
-        c->resizes++;
-    }
-    return NKML_OK;
-}
-
 // K0 + K1 on the context's stream: read starts and 2-bit packing of one batch.
 int run_prepare(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases)
 {
@@ -1430,11 +1433,104 @@ int run_kmerise(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, ui
     return NKML_OK;
 }
 
-// End of a batch's counting passes: the one host wait (for the number of crossing occurrences), then sort + rank.
-// Exactly one of d_flags (byte flags per position) / d_wflags (word flags) is given.
-int finish_counting(nkml_ctx *c, int n_ev, uint64_t keys_timed, uint8_t *d_flags, uint32_t *d_wflags)
+int rank_collected(nkml_ctx *c, uint8_t *d_flags, uint32_t *d_wflags);
+void reserve_next_table(nkml_ctx *c);
+
+// Growth of the hashed table (expand_local_hash_table, normalise_kmers_multi_large.c:1055-1108; load factor 0.8, :143, 933).
+// The table must have room for every key a counting pass can add before the pass starts, and a pass of `incoming`
+// positions can add that many.  What is stored is only known on the device, so the host keeps an upper bound
+// (the last fetched count plus every position enqueued since) and fetches the true count - one short wait - only when
+// the bound says the next pass might not fit.  The table then doubles until it does.  The next table is allocated
+// ahead of time where possible (reserve_next_table, called between batches), so that a growth inside a batch finds
+// its memory waiting and only has to rehash.  While old and new table coexist the path holds 3x the old table's bytes.
+// d_flags / d_wflags: where the batch's flags go, if a batch is being counted (see rank_collected).
+int ensure_capacity(nkml_ctx *c, uint64_t incoming, uint8_t *d_flags, uint32_t *d_wflags)
+{
+    if (c->direct) return NKML_OK;
+    if ((double)(c->used_bound + incoming) < (double)c->capacity * 0.8) { c->used_bound += incoming; return NKML_OK; }
+    int rc = fetch_counters(c); // waits for everything enqueued so far
+    if (rc != NKML_OK) return rc;
+    uint64_t used = c->h_ctr->unique;
+    if ((double)(used + incoming) >= (double)c->capacity * 0.8 && (d_flags || d_wflags)) {
+        // the crossing occurrences collected by the batch's earlier passes name their k-mers by slot: rank them before the
+        // slots move
+        if ((rc = rank_collected(c, d_flags, d_wflags)) != NKML_OK) return rc;
+    }
+    while ((double)(used + incoming) >= (double)c->capacity * 0.8) {
+        uint64_t ncap = c->capacity * 2;
+        Slot *ns = nullptr;
+        if (c->spare_slots && c->spare_capacity == ncap) {
+            ns = c->spare_slots;
+            c->spare_slots = nullptr;
+            c->spare_capacity = 0;
+        } else {
+            if (c->spare_slots) { hipFree(c->spare_slots); c->spare_slots = nullptr; c->spare_capacity = 0; }
+            HIPCHK(c, hipMalloc(&ns, ncap * sizeof(Slot)));
+        }
+        HIPCHK(c, zero_device(ns, ncap * sizeof(Slot), c->stream));
+        hipLaunchKernelGGL(k_rehash, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, ns, ncap - 1, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->slots));
+        c->slots = ns;
+        c->capacity = ncap;
+        c->resizes++;
+    }
+    c->used_bound = used + incoming;
+    return NKML_OK;
+}
+
+// Between batches (the counters have just been fetched): once the table is 40 % full the next doubling is near, so
+// its memory is taken now, outside the counting passes.  Failing to get it is not an error here; ensure_capacity asks
+// again when it needs it.
+void reserve_next_table(nkml_ctx *c)
+{
+    if (c->direct || c->partitioned || c->spare_slots) return;
+    c->used_bound = c->h_ctr->unique;
+    if ((double)c->h_ctr->unique < (double)c->capacity * 0.4) return;
+    Slot *ns = nullptr;
+    if (hipMalloc(&ns, c->capacity * 2 * sizeof(Slot)) != hipSuccess) { (void)hipGetLastError(); return; }
+    c->spare_slots = ns;
+    c->spare_capacity = c->capacity * 2;
+}
+
+// Sort + rank of the crossing occurrences collected so far (the counters have just been fetched): exact stream-order
+// ranks for them, HIGH where the rank reaches depth.  Exactly one of d_flags (byte flags per position) / d_wflags (word
+// flags) is given.  A k-mer crosses in one counting pass only and is saturated - its count frozen - from the next pass on,
+// so this may run after any pass that follows the crossing, not only at the end of the batch.
+int rank_collected(nkml_ctx *c, uint8_t *d_flags, uint32_t *d_wflags)
 {
     const uint32_t depth = (uint32_t)c->cfg.depth;
+    uint32_t n_occ = c->h_ctr->n_occ;
+    if (!n_occ) return NKML_OK;
+    int idbits = 0;
+    while (idbits < 64 && (c->capacity - 1) >> idbits) idbits++;
+    if (c->posbits + idbits > 64) return fail(c, NKML_E_ARG, "table and batch too large for 64-bit (k-mer, position) composites");
+    size_t tmp = c->sort_tmp_bytes;
+    HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, tmp, c->d_occ, c->d_occ_sorted, (size_t)n_occ, 0u, (unsigned)(c->posbits + idbits),
+                                       c->stream));
+    const uint32_t g = blocks_for(n_occ);
+    if (d_flags) {
+        if (c->direct)
+            hipLaunchKernelGGL((k_rank<DirectTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, DirectTable{c->counts}, depth, d_flags);
+        else
+            hipLaunchKernelGGL((k_rank<HashedTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, HashedTable{c->slots}, depth, d_flags);
+    } else {
+        if (c->direct)
+            hipLaunchKernelGGL((k_rank_words<DirectTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, DirectTable{c->counts}, depth, d_wflags);
+        else
+            hipLaunchKernelGGL((k_rank_words<HashedTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, HashedTable{c->slots}, depth, d_wflags);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->n_occ, 0, sizeof(unsigned int), c->stream));
+    c->h_ctr->n_occ = 0;
+    c->crossing_occ += n_occ;
+    return NKML_OK;
+}
+
+// End of a batch's counting passes: the one host wait (for the number of crossing occurrences), then sort + rank.
+int finish_counting(nkml_ctx *c, int n_ev, uint64_t keys_timed, uint8_t *d_flags, uint32_t *d_wflags)
+{
     int rc;
     if ((rc = fetch_counters(c)) != NKML_OK) return rc;
     if (c->h_ctr->probe_overflow) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
@@ -1445,30 +1541,9 @@ int finish_counting(nkml_ctx *c, int n_ev, uint64_t keys_timed, uint8_t *d_flags
     }
     c->count_launches += n_ev;
     c->count_keys += keys_timed;
-    uint32_t n_occ = c->h_ctr->n_occ;
-    if (n_occ) {
-        int idbits = 0;
-        while (idbits < 64 && (c->capacity - 1) >> idbits) idbits++;
-        if (c->posbits + idbits > 64) return fail(c, NKML_E_ARG, "table and batch too large for 64-bit (k-mer, position) composites");
-        size_t tmp = c->sort_tmp_bytes;
-        HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, tmp, c->d_occ, c->d_occ_sorted, (size_t)n_occ, 0u, (unsigned)(c->posbits + idbits),
-                                           c->stream));
-        const uint32_t g = blocks_for(n_occ);
-        if (d_flags) {
-            if (c->direct)
-                hipLaunchKernelGGL((k_rank<DirectTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, DirectTable{c->counts}, depth, d_flags);
-            else
-                hipLaunchKernelGGL((k_rank<HashedTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, HashedTable{c->slots}, depth, d_flags);
-        } else {
-            if (c->direct)
-                hipLaunchKernelGGL((k_rank_words<DirectTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, DirectTable{c->counts}, depth, d_wflags);
-            else
-                hipLaunchKernelGGL((k_rank_words<HashedTable>), g, 256, 0, c->stream, c->d_occ_sorted, n_occ, c->posbits, HashedTable{c->slots}, depth, d_wflags);
-        }
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->n_occ, 0, sizeof(unsigned int), c->stream));
-        c->crossing_occ += n_occ;
-    }
+    if (d_flags || d_wflags)
+        if ((rc = rank_collected(c, d_flags, d_wflags)) != NKML_OK) return rc;
+    reserve_next_table(c);
     return NKML_OK;
 }
 
@@ -1496,12 +1571,12 @@ int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags)
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0;
     const int exact = (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0;
     int rc;
-    if ((rc = ensure_capacity(c, n)) != NKML_OK) return rc;
     if (n > (1ull << c->posbits)) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
     int n_ev = 0;
     uint64_t keys_timed = 0;
     for (uint64_t a = 0; a < n; a += c->chunk) {
         uint64_t len = n - a < c->chunk ? n - a : c->chunk;
+        if ((rc = ensure_capacity(c, len, d_flags, nullptr)) != NKML_OK) return rc; // room for every key this pass can add
         const bool timed = profile && n_ev < 64;
         if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
         if (c->direct)
@@ -1539,9 +1614,9 @@ int run_fused(nkml_ctx *c, uint64_t n_bases, bool seeding)
     const bool canon = c->cfg.canonical != 0;
     const uint64_t n_words = (n_bases + 15) / 16;
     int rc;
-    if ((rc = ensure_capacity(c, n_words * 16)) != NKML_OK) return rc;
-    const uint64_t mask = c->capacity - 1; // after the table has grown, not before
     if (seeding) {
+        if ((rc = ensure_capacity(c, n_words * 16, nullptr, nullptr)) != NKML_OK) return rc;
+        const uint64_t mask = c->capacity - 1; // after the table has grown, not before
 #define SEED_LAUNCH(CANON, DIRECT) hipLaunchKernelGGL((k_seed_words<CANON, DIRECT>), GRID_PERSIST, 256, 0, c->stream, c->d_packed, c->d_startbits, \
                                                       n_bases, n_words, k, c->counts, c->slots, mask, c->d_ctr)
         if (c->direct) { if (canon) SEED_LAUNCH(true, true); else SEED_LAUNCH(false, true); }
@@ -1555,6 +1630,8 @@ int run_fused(nkml_ctx *c, uint64_t n_bases, bool seeding)
     const uint64_t chunk_words = c->chunk / 16;
     for (uint64_t wa = 0; wa < n_words; wa += chunk_words) {
         const uint64_t wb = wa + chunk_words < n_words ? wa + chunk_words : n_words;
+        if ((rc = ensure_capacity(c, (wb - wa) * 16, nullptr, c->d_wflags)) != NKML_OK) return rc; // room for every key this pass can add
+        const uint64_t mask = c->capacity - 1; // after the table has grown, not before
         const bool timed = profile && n_ev < 64;
         if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * n_ev], c->stream));
         if (c->direct) {
@@ -1864,7 +1941,7 @@ void nkml_destroy(nkml_ctx *c)
     if (!c) return;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots);
+    hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots); hipFree(c->spare_slots);
     hipFree(c->pt_table); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flagsA);
     hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
     hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB);
@@ -1894,6 +1971,10 @@ int nkml_reset(nkml_ctx *c)
     if (rc != NKML_OK) return rc;
     memset(c->h_ctr, 0, sizeof(Counters));
     c->pending = false;
+    c->pending_check = false;
+    c->pt_timing_pending = false;
+    c->staged_pending = false;
+    c->used_bound = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return NKML_OK;
 }
@@ -1956,6 +2037,26 @@ int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->partitioned) return run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, 0, d_flags, false);
     return run_count(c, d_keys, n_keys, d_flags);
+}
+
+int nkml_seed_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys)
+{
+    if (!c || !d_keys || (n_keys & 15)) return NKML_E_ARG;
+    if (n_keys == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc;
+    if (c->partitioned) {
+        if ((rc = run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, 0, nullptr, true)) != NKML_OK) return rc;
+        return fetch_counters(c);
+    }
+    if ((rc = ensure_capacity(c, n_keys, nullptr, nullptr)) != NKML_OK) return rc;
+    if (c->direct)
+        hipLaunchKernelGGL((k_seed_keys<uint32_t, true>), GRID_PERSIST, 256, 0, c->stream, (const uint32_t *)d_keys, n_keys, c->counts, c->slots, 0ull, c->d_ctr);
+    else
+        hipLaunchKernelGGL((k_seed_keys<unsigned long long, false>), GRID_PERSIST, 256, 0, c->stream, (const unsigned long long *)d_keys, n_keys,
+                           c->counts, c->slots, c->capacity - 1, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    return finish_counting(c, 0, 0, nullptr, nullptr);
 }
 
 int nkml_reduce_reads_device(nkml_ctx *c, const void *d_keys, const uint8_t *d_flags, const uint64_t *d_offsets, uint32_t n_reads,
@@ -2297,28 +2398,20 @@ int nkml_unroute_flags_device(nkml_ctx *c, const uint8_t *d_recv_flags, const ui
     return NKML_OK;
 }
 
-int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries)
+static int dump_table_into(nkml_ctx *c, unsigned long long *d_codes, uint32_t *d_cnts, unsigned long long *d_n, uint64_t *codes,
+                           uint32_t *counts, uint64_t max_entries, uint64_t *n_entries)
 {
-    if (!c || !n_entries || (max_entries && (!codes || !counts))) return NKML_E_ARG;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-    unsigned long long *d_codes = nullptr, *d_n = nullptr;
-    uint32_t *d_cnts = nullptr;
-    uint64_t room = max_entries ? max_entries : 1;
-    HIPCHK(c, hipMalloc(&d_codes, room * sizeof(unsigned long long)));
-    HIPCHK(c, hipMalloc(&d_cnts, room * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc(&d_n, sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
-    if (c->partitioned)
-    {
+    if (c->partitioned) {
         if (c->pt_wide)
             hipLaunchKernelGGL((k_pt_dump<uint16_t>), GRID_PERSIST, 256, 0, c->stream, (const uint16_t *)c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
         else
             hipLaunchKernelGGL((k_pt_dump<uint8_t>), GRID_PERSIST, 256, 0, c->stream, (const uint8_t *)c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
-    }
-    else if (c->direct)
+    } else if (c->direct) {
         hipLaunchKernelGGL(k_dump_direct, GRID_PERSIST, 256, 0, c->stream, c->counts, c->extra, c->capacity, d_codes, d_cnts, max_entries, d_n);
-    else
+    } else {
         hipLaunchKernelGGL(k_dump_hashed, GRID_PERSIST, 256, 0, c->stream, c->slots, c->capacity, d_codes, d_cnts, max_entries, d_n);
+    }
     HIPCHK(c, hipGetLastError());
     unsigned long long n = 0;
     HIPCHK(c, hipMemcpyAsync(&n, d_n, sizeof n, hipMemcpyDeviceToHost, c->stream));
@@ -2329,8 +2422,26 @@ int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max
         HIPCHK(c, hipMemcpy(counts, d_cnts, take * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     *n_entries = n;
-    hipFree(d_codes); hipFree(d_cnts); hipFree(d_n);
     return NKML_OK;
+}
+
+int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries)
+{
+    if (!c || !n_entries || (max_entries && (!codes || !counts))) return NKML_E_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    unsigned long long *d_codes = nullptr, *d_n = nullptr;
+    uint32_t *d_cnts = nullptr;
+    const uint64_t room = max_entries ? max_entries : 1;
+    int rc = NKML_OK;
+    hipError_t e;
+    // the three device buffers are freed on every way out
+    if ((e = hipMalloc(&d_codes, room * sizeof(unsigned long long))) != hipSuccess || (e = hipMalloc(&d_cnts, room * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc(&d_n, sizeof(unsigned long long))) != hipSuccess)
+        rc = fail(c, e == hipErrorOutOfMemory ? NKML_E_NOMEM : NKML_E_HIP, "table dump: %s", hipGetErrorString(e));
+    else
+        rc = dump_table_into(c, d_codes, d_cnts, d_n, codes, counts, max_entries, n_entries);
+    hipFree(d_codes); hipFree(d_cnts); hipFree(d_n);
+    return rc;
 }
 
 } // extern "C"

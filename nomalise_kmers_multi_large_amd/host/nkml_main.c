@@ -13,7 +13,12 @@
  * Differences, all deliberate:
  *   --cpu is accepted and ignored: there is one shared k-mer table on the device, so the depth is not divided
  *   by the thread count (ref:674) and there is a single output file pair named ..._thread0.fastq;
- *   counts are exact (what the reference computes when its table has no collisions, i.e. -m 16 at k=15);
+ *   counts are exact: that is what the reference computes only while its own table is collision-free (capacity == 4^k:
+ *   k <= 13 always, -m 4 at k=14, -m 16 at k=15, ref:676-684).  With a smaller table - its default at k >= 14, any table
+ *   at k > 16 - the reference's probe path (ref:1009-1047) perturbs counts and the reported unique k-mers, so outputs are
+ *   byte-identical to it only where those collisions do not flip a decision (every fixture the reference ships; not
+ *   guaranteed on large inputs: 0.07 % of 2 M synthetic pairs differ at k=15, 0.017 % at k=25).  A one-line notice on
+ *   stderr says when the run is in that regime;
  *   lines longer than 1023 bytes are an error instead of being split (ref:139, 394-409).
  */
 #define _GNU_SOURCE
@@ -184,6 +189,10 @@ static int parse_arguments(int argc, char **argv)
         printf("Initial hash table size set to %'zu (maximum for k=%d is %'zu); memory ~ %'0.2f Gb for each of %d threads (~ %'d Gb total))\n\n",
                cap, cfg.ksize, pow4(cfg.ksize), mem_per_cpu, cfg.cpus, total);
     }
+    if (cfg.cpus > 0 && cfg.ksize >= 5 && cfg.ksize <= 31 && reference_capacity(cfg.memory, cfg.cpus, cfg.ksize) < pow4(cfg.ksize))
+        fprintf(stderr, "Note: k-mers are counted exactly here; the reference program with this --memory_start holds %'zu slots for 4^%d "
+                        "possible k-mers, so its own counts (and, rarely, keep/skip decisions on large inputs) are perturbed by table collisions\n",
+                reference_capacity(cfg.memory, cfg.cpus, cfg.ksize), cfg.ksize);
     /* ref:704-743 */
     if (cfg.n_fwd == 0 || (cfg.n_rev == 0 && !cfg.single)) {
         fprintf(stderr, "Error: no fwd (%d) or reverse (%d) files provided\n", cfg.n_fwd, cfg.n_rev);
@@ -385,7 +394,8 @@ static inline double now_s(void)
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 #define TIMED(slot, stmt) do { double t0_ = timing_on ? now_s() : 0; stmt; if (timing_on) t_phase[slot] += now_s() - t0_; } while (0)
-static nkml_ctx *ctx;
+static nkml_ctx *ctx;     /* one device ... */
+static nkml_multi *mctx;  /* ... or one table over several (NKML_DEVICES): exactly one of the two is set */
 static int out_fd[2] = {-1, -1};  /* forward / reverse output files */
 static off_t out_off[2];          /* bytes written so far */
 static struct totals tot;
@@ -393,15 +403,27 @@ static struct totals tot;
 static void die_nkml(const char *what, int rc)
 {
     fflush(NULL);
-    fprintf(stderr, "Error: %s: %s (%s)\n", what, nkml_strerror(rc), ctx ? nkml_last_error(ctx) : "");
+    fprintf(stderr, "Error: %s: %s (%s)\n", what, nkml_strerror(rc), mctx ? nkml_multi_last_error(mctx) : ctx ? nkml_last_error(ctx) : "");
     exit(EXIT_FAILURE);
+}
+
+/* the engine behind the record loop: the single-device context or the multi-device one, same calls */
+static int eng_host_staging(uint8_t **seq, uint64_t **off) { return mctx ? nkml_multi_host_staging(mctx, seq, off) : nkml_host_staging(ctx, seq, off); }
+static int eng_wait_staged(void) { return mctx ? nkml_multi_wait_staged(mctx) : nkml_wait_staged(ctx); }
+static int eng_submit(const uint8_t *seq, const uint64_t *off, uint32_t n) { return mctx ? nkml_multi_submit(mctx, seq, off, n) : nkml_submit(ctx, seq, off, n); }
+static int eng_collect(int32_t *high, int32_t *total) { return mctx ? nkml_multi_collect(mctx, high, total) : nkml_collect(ctx, high, total); }
+static int eng_seed(const uint8_t *seq, const uint64_t *off, uint32_t n) { return mctx ? nkml_multi_seed(mctx, seq, off, n) : nkml_seed(ctx, seq, off, n); }
+static int eng_stats(nkml_stats *st) { return mctx ? nkml_multi_get_stats(mctx, st) : nkml_get_stats(ctx, st); }
+static int eng_dump(uint64_t *codes, uint32_t *counts, uint64_t max, uint64_t *n)
+{
+    return mctx ? nkml_multi_dump_table(mctx, codes, counts, max, n) : nkml_dump_table(ctx, codes, counts, max, n);
 }
 
 static void batch_alloc(uint32_t cap_reads, uint64_t cap_bases)
 {
     B.cap_reads = cap_reads;
     B.cap_bases = cap_bases;
-    int rc = nkml_host_staging(ctx, &B.seq, &B.offsets);
+    int rc = eng_host_staging(&B.seq, &B.offsets);
     if (rc != NKML_OK) die_nkml("staging", rc);
     for (int w = 0; w < 2; w++) {
         WIN[w].rec = malloc((size_t)cap_reads * sizeof(uint32_t));
@@ -593,7 +615,7 @@ static void submit_window(void)
     if (W->n_units == 0) return;
     int rc = 0;
     TIMED(3, {
-        rc = nkml_submit(ctx, B.seq, B.offsets, W->n_reads);
+        rc = eng_submit(B.seq, B.offsets, W->n_reads);
         if (rc != NKML_OK) die_nkml("submit", rc);
     });
 }
@@ -604,7 +626,7 @@ static void finish_window(void)
     if (W->n_units == 0) return;
     int rc = 0;
     TIMED(3, {
-        rc = nkml_collect(ctx, W->high, W->total);
+        rc = eng_collect(W->high, W->total);
         if (rc != NKML_OK) die_nkml("collect", rc);
     });
 }
@@ -724,7 +746,7 @@ static void process_files(const struct mapped *fwd, const struct mapped *rev)
         const bool more = size_window(fwd, rev, &pos_f, &pos_r, &bytes_per_rec, &bad, &bad_rev);
         if (more) {
             /* the staging area is the library's: the previous window's copy to the device has to be over */
-            if (prev) { int rc = nkml_wait_staged(ctx); if (rc != NKML_OK) die_nkml("wait", rc); }
+            if (prev) { int rc = eng_wait_staged(); if (rc != NKML_OK) die_nkml("wait", rc); }
             TIMED(2, parallel_run(stage_records, NULL));
         }
         if (prev) { W = prev; finish_window(); W = cur; }
@@ -814,7 +836,7 @@ static void seed_file(const char *name, int limit)
         W->n_bases = bases;
         if (units) {
             parallel_run(stage_records, NULL);
-            int rc = nkml_seed(ctx, B.seq, B.offsets, W->n_reads);
+            int rc = eng_seed(B.seq, B.offsets, W->n_reads);
             if (rc != NKML_OK) die_nkml("seed", rc);
         }
         done += units;
@@ -827,7 +849,7 @@ static void seed_file(const char *name, int limit)
     }
     if (cfg.verbose) {
         nkml_stats st;
-        nkml_get_stats(ctx, &st);
+        eng_stats(&st);
         printf("%'zu records with %'zu kmers seeded\n", done, (size_t)st.unique_kmers);
     }
     unmap_file(&m);
@@ -847,13 +869,13 @@ static char *output_name(const char *base, int k, int depth, int thread, const c
 static void print_table(const char *identifier, int thread)
 {
     uint64_t n = 0;
-    int rc = nkml_dump_table(ctx, NULL, NULL, 0, &n);
+    int rc = eng_dump(NULL, NULL, 0, &n);
     if (rc != NKML_OK) die_nkml("dump", rc);
     uint64_t *codes = malloc((n ? n : 1) * sizeof(uint64_t));
     uint32_t *counts = malloc((n ? n : 1) * sizeof(uint32_t));
     if (!codes || !counts) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
     uint64_t got = 0;
-    rc = nkml_dump_table(ctx, codes, counts, n, &got);
+    rc = eng_dump(codes, counts, n, &got);
     if (rc != NKML_OK) die_nkml("dump", rc);
     if (got < n) n = got;
     char base[32];
@@ -898,10 +920,35 @@ int main(int argc, char **argv)
         if (n_threads > MAX_THREADS) n_threads = MAX_THREADS;
     }
     timing_on = getenv("NKML_TIMING") != NULL;
+    /* NKML_DEVICES: a number n (devices 0 .. n-1) or a comma-separated list of HIP ordinals, one per table shard (an
+     * ordinal may repeat: shards then share that GPU).  More than one entry: one k-mer table sharded over them. */
+    int32_t devices[64];
+    uint32_t n_devices = 0;
+    if (getenv("NKML_DEVICES")) {
+        const char *p = getenv("NKML_DEVICES");
+        if (!strchr(p, ',')) {
+            const long n = strtol(p, NULL, 10);
+            for (long i = 0; i < n && i < 64; i++) devices[n_devices++] = (int32_t)i;
+        } else {
+            while (*p && n_devices < 64) {
+                char *end;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                devices[n_devices++] = (int32_t)d;
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
+    }
     int rc = 0;
     TIMED(7, {
-        rc = nkml_create(&nc, &ctx);
-        if (rc != NKML_OK) die_nkml("cannot set up the GPU k-mer table", rc);
+        if (n_devices > 1) {
+            rc = nkml_multi_create(&nc, devices, n_devices, &mctx);
+            if (rc != NKML_OK) die_nkml("cannot set up the k-mer table over the GPUs of NKML_DEVICES", rc);
+        } else {
+            if (n_devices == 1) nc.device = devices[0];
+            rc = nkml_create(&nc, &ctx);
+            if (rc != NKML_OK) die_nkml("cannot set up the GPU k-mer table", rc);
+        }
         batch_alloc(nc.max_batch_reads, nc.max_batch_bases);
     });
 
@@ -956,7 +1003,7 @@ int main(int argc, char **argv)
         process_files(&mf, paired ? &mr : NULL);
         clock_gettime(CLOCK_MONOTONIC, &f1);
         nkml_stats st;
-        if ((rc = nkml_get_stats(ctx, &st)) != NKML_OK) die_nkml("stats", rc);
+        if ((rc = eng_stats(&st)) != NKML_OK) die_nkml("stats", rc);
         if ((size_t)st.unique_kmers > max_unique) max_unique = (size_t)st.unique_kmers;
         double secs = (double)(f1.tv_sec - f0.tv_sec) + 1e-9 * (double)(f1.tv_nsec - f0.tv_nsec);
         /* ref:1752-1759 (rate measured with a finer clock than the reference's 1 s) and ref:1911 */
@@ -991,7 +1038,8 @@ int main(int argc, char **argv)
         for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.3f", t_name[i], t_phase[i]);
         fprintf(stderr, " (threads %d)\n", n_threads);
     }
-    nkml_destroy(ctx);
+    if (mctx) nkml_multi_destroy(mctx);
+    else nkml_destroy(ctx);
     free(name_f);
     free(name_r);
     return 0;

@@ -217,3 +217,87 @@ class KmerNormaliser:
         self._chk(self.lib.nkml_dump_table(self.h, codes.ctypes.data, counts.ctypes.data, max_entries, ctypes.byref(n)))
         m = min(n.value, max_entries)
         return codes[:m], counts[:m], n.value
+
+
+class MultiDeviceNormaliser:
+    """ctypes face of the nkml_multi_* functions: one k-mer table sharded over several GPUs, driven from this process
+    (what the command-line host uses with NKML_DEVICES).  `devices` lists one HIP ordinal per table shard; an ordinal may
+    repeat (shards then share that GPU).  Host buffers in, per-read counters out, as KmerNormaliser.process_batch."""
+
+    def __init__(self, devices, ksize=15, depth=100, coverage=0.9, canonical=False, memory_gb=0,
+                 max_batch_reads=1 << 20, max_batch_bases=1 << 28, chunk_bases=0, flags=0):
+        self.lib = B.load_library()
+        self.ksize, self.depth, self.canonical = int(ksize), int(depth), bool(canonical)
+        self.coverage = np.float32(coverage)
+        cfg = B.Config(self.ksize, self.depth, int(self.canonical), 0, int(memory_gb), int(max_batch_reads),
+                       int(max_batch_bases), int(chunk_bases), int(flags))
+        devs = (ctypes.c_int32 * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self.lib.nkml_multi_create(ctypes.byref(cfg), devs, len(devices), ctypes.byref(h))
+        self.h = h if h.value else None
+        if rc != B.NKML_OK:
+            msg = self._err(rc)
+            self.close()
+            raise B.NkmlError(rc, msg)
+
+    def _err(self, rc):
+        msg = self.lib.nkml_strerror(rc).decode()
+        if self.h:
+            msg += ": " + self.lib.nkml_multi_last_error(self.h).decode()
+        return msg
+
+    def _chk(self, rc):
+        if rc != B.NKML_OK:
+            raise B.NkmlError(rc, self._err(rc))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nkml_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        self._chk(self.lib.nkml_multi_reset(self.h))
+
+    def stats(self):
+        st = B.Stats()
+        self._chk(self.lib.nkml_multi_get_stats(self.h, ctypes.byref(st)))
+        return st.as_dict()
+
+    @property
+    def unique_kmers(self):
+        return self.stats()["unique_kmers"]
+
+    def process_batch(self, seq, offsets):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        high = np.zeros(n, dtype=np.int32)
+        total = np.zeros(n, dtype=np.int32)
+        self._chk(self.lib.nkml_multi_submit(self.h, seq.ctypes.data, offsets.ctypes.data, n))
+        self._chk(self.lib.nkml_multi_collect(self.h, high.ctypes.data, total.ctypes.data))
+        return high, total
+
+    def seed_batch(self, seq, offsets):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(self.lib.nkml_multi_seed(self.h, seq.ctypes.data, offsets.ctypes.data, len(offsets) - 1))
+
+    def dump_table(self, max_entries=1 << 24):
+        codes = np.zeros(max_entries, dtype=np.uint64)
+        counts = np.zeros(max_entries, dtype=np.uint32)
+        n = ctypes.c_uint64(0)
+        self._chk(self.lib.nkml_multi_dump_table(self.h, codes.ctypes.data, counts.ctypes.data, max_entries, ctypes.byref(n)))
+        m = min(n.value, max_entries)
+        return codes[:m], counts[:m], n.value

@@ -163,6 +163,17 @@ class ReplicatedReadsNormaliser:
             return None
         return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
+    def _agree(self, err, like):
+        """Every rank calls this after the stage that can fail on one rank alone (err = its exception or None): all raise,
+        or none - a rank left alone with its exception would leave its peers waiting in the next collective."""
+        cdev = "cpu" if self.stage_through_host or not like.is_cuda else like.device
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            if err is not None:
+                raise err
+            raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or a batch beyond the sizes it was set up for)")
+
     def _sum(self, t, everywhere=True):
         """Sum over the ranks, in place; with everywhere=False only rank 0 is owed the result (half the traffic)."""
         op = (lambda v: dist.all_reduce(v, group=self.group)) if everywhere else (lambda v: dist.reduce(v, dst=0, group=self.group))
@@ -230,7 +241,12 @@ class ReplicatedReadsNormaliser:
         goff = global_offsets([x["off_all"][r * slot:(r + 1) * slot] for r in range(W)], x["reads"], x["bases"], x["region"], x["fillers"])
         if then is not None:
             self._ahead = self._start_exchange(*then)
-        counters = eng.process_packed(x["words_all"], goff, x["total_reads"], W * x["region"] * 16)
+        err = None
+        try:
+            counters = eng.process_packed(x["words_all"], goff, x["total_reads"], W * x["region"] * 16)
+        except Exception as e:   # e.g. a byte outside ACGTN among this rank's reads: only this rank's context knows
+            err = e
+        self._agree(err, seq)
         self._sum_counters(counters, x["narrow"])
         if self.root_only and self.rank != 0:
             return None, None, None

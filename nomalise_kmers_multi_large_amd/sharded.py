@@ -220,15 +220,31 @@ class ShardedNormaliser:
             q.wait()
         return [b.to(packed.device) for b in bufs] if host else bufs
 
-    def _exchange_counts(self, send_counts, like):
-        """What every peer sends here, and the largest segment of the whole exchange (for the round count)."""
+    def _exchange_counts(self, send_counts, like, failed=False, cap=None):
+        """What every peer sends here, the largest segment of the whole exchange (for the round count), and whether the
+        step has to stop: a rank whose routing failed (`failed`: e.g. a read with a byte outside ACGTN) or that would
+        receive more keys than it was sized for (`cap`) must not be left alone with its exception while its peers walk
+        into the next collective, so the outcome travels with the counts and every rank learns it here."""
         cdev = "cpu" if self.stage_through_host or not like.is_cuda else like.device
         sc = torch.tensor(send_counts, dtype=torch.int64, device=cdev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)
-        peak = sc.max().reshape(1).clone()
-        dist.all_reduce(peak, op=dist.ReduceOp.MAX, group=self.group)
-        return [int(x) for x in rc.tolist()], int(peak.item())
+        recv = [int(x) for x in rc.tolist()]
+        too_many = cap is not None and sum(recv) > cap
+        agg = torch.stack([sc.max(), torch.tensor(1 if (failed or too_many) else 0, dtype=torch.int64, device=cdev)])
+        dist.all_reduce(agg, op=dist.ReduceOp.MAX, group=self.group)
+        peak, stop = agg.tolist()
+        return recv, int(peak), bool(stop), too_many
+
+    def _agree(self, err, like):
+        """Every rank calls this after a stage that can fail on one rank alone (err = its exception or None): all raise, or none."""
+        cdev = "cpu" if self.stage_through_host or not like.is_cuda else like.device
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            if err is not None:
+                raise err
+            raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or a batch beyond the sizes it was set up for)")
 
     def _start_exchange(self, seq, offsets, n_reads, n_bases):
         """Everything of a step that does not need the table: k-mers, routing, the all-to-all of keys (left in flight)."""
@@ -237,13 +253,23 @@ class ShardedNormaliser:
         if hasattr(eng, "use_buffers"):
             eng.use_buffers(self._buffer)
         x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases)}
-        if hasattr(eng, "kmerise_route"):
-            send_keys, x["send_src"], x["send_counts"], x["n_positions"] = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
-        else:
-            keys = eng.kmerise(seq, offsets, n_reads, n_bases)
-            send_keys, x["send_src"], x["send_counts"] = eng.route(keys, W)
-            x["n_positions"] = keys.numel()
-        x["recv_counts"], x["peak"] = self._exchange_counts(x["send_counts"], send_keys)
+        err = None
+        try:
+            if hasattr(eng, "kmerise_route"):
+                send_keys, x["send_src"], x["send_counts"], x["n_positions"] = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
+            else:
+                keys = eng.kmerise(seq, offsets, n_reads, n_bases)
+                send_keys, x["send_src"], x["send_counts"] = eng.route(keys, W)
+                x["n_positions"] = keys.numel()
+        except Exception as e:   # this rank cannot go on, but its peers have to hear of it before anyone raises
+            err, send_keys, x["send_counts"] = e, seq[:0], [0] * W
+        x["recv_counts"], x["peak"], stop, too_many = self._exchange_counts(x["send_counts"], seq, err is not None, getattr(eng, "cap", None))
+        if stop:
+            if err is not None:
+                raise err
+            if too_many:
+                raise RuntimeError("received %d keys, more than the %d this rank was sized for" % (sum(x["recv_counts"]), eng.cap))
+            raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or more keys than it was sized for)")
         x["recv_keys"] = eng.recv_buffer(sum(x["recv_counts"]))
         x["owed"] = self._all_to_all_start(x["recv_keys"], send_keys, x["recv_counts"], x["send_counts"], x["peak"])
         x["alive"] = (send_keys, seq, offsets)
@@ -265,7 +291,12 @@ class ShardedNormaliser:
         self._all_to_all_finish(x["owed"])
         if then is not None:
             self._ahead = self._start_exchange(*then)
-        recv_flags = eng.count(x["recv_keys"])
+        err = None
+        try:
+            recv_flags = eng.count(x["recv_keys"])
+        except Exception as e:   # e.g. the table shard cannot grow any further
+            err = e
+        self._agree(err, seq)
         back = eng.back_buffer(sum(x["send_counts"]))
         self._all_to_all(back, recv_flags, x["send_counts"], x["recv_counts"], x["peak"])
         flags = eng.unroute(back, x["send_src"], x["n_positions"])

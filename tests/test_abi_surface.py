@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = binding.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.nkml_abi_version() == 4
+    assert lib.nkml_abi_version() == 5
     assert lib.nkml_strerror(0) == b"ok" and lib.nkml_strerror(-4) == b"sequence byte outside ACGTN"
 
 

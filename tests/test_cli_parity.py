@@ -80,9 +80,32 @@ def test_argument_validation_without_gpu(tmp_path, args, needle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(META))
 def test_cli_against_reference_runs(name, inputs_dir, tmp_path, oracle_lib):
+    check_cli_run(name, inputs_dir, tmp_path, {})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(META))
+def test_cli_on_two_table_shards_against_reference_runs(name, inputs_dir, tmp_path, oracle_lib):
+    """The same runs with the k-mer table sharded over two devices from the C host (NKML_DEVICES): on a one-GPU machine the
+    two shards share the GPU and device-to-device copies stand in for the links; outputs, report and per-record counters
+    must not change."""
+    check_cli_run(name, inputs_dir, tmp_path, {"NKML_DEVICES": "0,0", "NKML_TRANSPORT": "copy"})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["G7_mixed_k31_d50_fa", "G5_a1a2_b1b2_d4"])
+def test_cli_on_four_table_shards(name, inputs_dir, tmp_path, oracle_lib):
+    """The mixed single-end + paired-end k=31 --outformat fa run (four devices in the headline configuration) and a k=15 run
+    on four shards."""
+    check_cli_run(name, inputs_dir, tmp_path, {"NKML_DEVICES": "0,0,0,0", "NKML_TRANSPORT": "copy"})
+
+
+def check_cli_run(name, inputs_dir, tmp_path, extra_env):
     meta = META[name]
     args = [a.replace("REF_TEST/", inputs_dir + "/").replace("EDGE/", inputs_dir + "/") for a in meta["args"]]
-    r = run_cli(args + ["--debug", "2"], str(tmp_path), env={"NKML_BATCH_READS": "6000", "NKML_BATCH_BASES": "600000"})
+    env = {"NKML_BATCH_READS": "6000", "NKML_BATCH_BASES": "600000"}
+    env.update(extra_env)
+    r = run_cli(args + ["--debug", "2"], str(tmp_path), env=env)
     assert r.returncode == 0, r.stderr.decode()
     out = r.stdout.decode("latin-1").splitlines()
     # output files: same names, same bytes

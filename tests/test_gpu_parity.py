@@ -399,6 +399,27 @@ def test_sharded_normaliser_over_rccl_world_of_one(nk):
         dist.destroy_process_group()
 
 
+def test_k25_decisions_against_the_reference_at_scale(nk):
+    """k=25 --canonical on 2 M synthetic pairs against the decisions of the reference program itself (recorded by
+    tests/refdiff_k25.py, one bitmap per reference table size).  The reference's table is never collision-free at k > 16, so
+    a few decisions at the threshold differ from exact counting: 348 of 2 M with its default table; fewer the larger its
+    table, which is what pins the differences on its collisions.  The product runs with --memory_start 4 (a k > 16 context
+    with memory_gb > 0) and grows its table from there."""
+    from tests import refdiff_k25
+    maps = refdiff_k25.load_bitmaps()
+    assert maps, "tests/golden/refdiff_k25_*.npz missing"
+    keep, unique = refdiff_k25.product_keep(maps[0]["pairs"])
+    assert int(keep.sum()) == 883957 and unique == 33851135   # the exact model's answer (CPU oracle)
+    diffs = {}
+    for m in maps:
+        assert m["pairs"] == maps[0]["pairs"]
+        diffs[m["memory_gb"]] = int((keep != m["keep"]).sum())
+    assert diffs[0] == 348 and m["printed"] > 0
+    for gb, d in diffs.items():
+        if gb:
+            assert d < diffs[0], diffs   # a larger reference table collides less and disagrees less
+
+
 @pytest.mark.parametrize("k,canonical,batch_pairs,want_kept,want_unique", [
     (15, False, 2000000, 1011077, 28393181),   # one batch: 544 M k-mers through the partitioned path at its working size
     (15, False, 700000, 1011077, 28393181),    # ragged batches: the answer does not depend on the cuts
@@ -770,3 +791,62 @@ def test_multi_gpu_step_to_which_a_rank_brings_nothing(nk, mode):
             assert mg.stats()["unique_kmers"] == g.unique_kmers and int(want_h.sum()) > 0
     finally:
         dist.destroy_process_group()
+
+
+# ---- one table over several devices, driven from one process (nkml_multi_*, what the command line uses with NKML_DEVICES) ----
+@pytest.mark.parametrize("devices,transport,k,depth,canonical", [
+    ([0, 0], "copy", 15, 3, False),        # partitioned counting behind the exchange, two shards sharing the GPU
+    ([0, 0, 0], "copy", 15, 100, True),
+    ([0, 0], "copy", 11, 4, True),         # direct table, atomic path
+    ([0, 0], "copy", 25, 4, True),         # hashed table
+    ([0, 0, 0, 0], "copy", 31, 3, False),
+    ([0], "copy", 15, 3, False),           # a "multi" of one
+    ([0], "rccl", 21, 3, True),            # the RCCL send/receive transport with a world of one (all a one-GPU box can run)
+])
+def test_multi_device_table_equals_single_stream(nk, oracle_lib, devices, transport, k, depth, canonical):
+    from nomalise_kmers_multi_large_amd.normaliser import MultiDeviceNormaliser
+    rng = np.random.default_rng(900 + k + len(devices))
+    reads = random_reads(rng, 500, k, 4 * k + 40, b"AC") + random_reads(rng, 700, k, 200, b"ACGT", 0.01) \
+        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"G" * 64, b"C" * 33, b"N" * 40] * 3
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    o = oracle_lib(k, depth, canonical)
+    seeds = [r for r in reads[:200] if len(r) > k]   # the reference seeds with reads longer than k only
+    for r in seeds:
+        o.seed(r)
+    want = [o.read(r) for r in reads]
+    old = os.environ.get("NKML_TRANSPORT")
+    os.environ["NKML_TRANSPORT"] = transport
+    try:
+        with MultiDeviceNormaliser(devices, k, depth, 0.9, canonical, max_batch_reads=700, max_batch_bases=90000) as g:
+            seq, off = nk.KmerNormaliser._concat(seeds)
+            g.seed_batch(seq, off)
+            assert g.unique_kmers == o_unique_after_seeding(oracle_lib, k, depth, canonical, seeds)
+            high, total = [], []
+            for at in range(0, len(reads), 450):   # several ragged batches
+                seq, off = nk.KmerNormaliser._concat(reads[at:at + 450])
+                h, t = g.process_batch(seq, off)
+                high.append(h)
+                total.append(t)
+            np.testing.assert_array_equal(np.concatenate(high), [w[1] for w in want])
+            np.testing.assert_array_equal(np.concatenate(total), [w[2] for w in want])
+            assert g.unique_kmers == o.unique
+            codes, counts, n = g.dump_table()
+            assert n == o.unique and len(set(codes.tolist())) == n
+            # a read with a byte outside ACGTN stops the batch with the reference's error class, whatever shard it falls to
+            bad = reads[:40] + [b"ACGT" * 10 + b"x" + b"ACGT" * 10] + reads[40:80]
+            seq, off = nk.KmerNormaliser._concat(bad)
+            with pytest.raises(nk.NkmlError) as e:
+                g.process_batch(seq, off)
+            assert e.value.code == -4
+    finally:
+        if old is None:
+            os.environ.pop("NKML_TRANSPORT", None)
+        else:
+            os.environ["NKML_TRANSPORT"] = old
+
+
+def o_unique_after_seeding(oracle_lib, k, depth, canonical, seeds):
+    o = oracle_lib(k, depth, canonical)
+    for r in seeds:
+        o.seed(r)
+    return o.unique

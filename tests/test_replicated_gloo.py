@@ -158,3 +158,43 @@ def test_shard_rule_of_the_library_is_a_partition():
         share = np.bincount(s, minlength=n) / len(keys)
         assert np.abs(share - 1.0 / n).max() < 0.02
     assert lib.nkml_shard_of(1 << 33, 2) < 0 and lib.nkml_shard_of(5, 0) < 0
+
+
+def failing_worker(rank, world, port, q):
+    """Rank 1's counting raises (what a byte outside ACGTN among its reads does): both ranks must come back with an exception."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nomalise_kmers_multi_large_amd.replicated import ReplicatedReadsNormaliser
+
+        class Faulty(CheckerReplicaEngine):
+            def process_packed(self, words_all, offsets, n_reads, n_bases):
+                if rank == 1:
+                    raise ValueError("sequence byte outside ACGTN")
+                return super().process_packed(words_all, offsets, n_reads, n_bases)
+
+        rn = ReplicatedReadsNormaliser(Faulty(9, 3, False, world, rank), check_words=0, root_only=True)
+        seq, off = concat(make_reads(rank, 30, 9, 60))
+        try:
+            rn.process_step(torch.from_numpy(seq), torch.from_numpy(off), len(off) - 1, len(seq))
+            q.put((rank, "returned"))
+        except Exception as e:
+            q.put((rank, type(e).__name__ + ": " + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_rank_that_fails_stops_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "ValueError" in got[1] and "another rank stopped this step" in got[0]

@@ -178,3 +178,56 @@ def test_startup_check_notices_a_lossy_exchange_and_shrinks_the_rounds():
             Lossy(CheckerEngine(9, 3, False), max_message_bytes=12000, check_elems=2000)
     finally:
         dist.destroy_process_group()
+
+
+def failing_worker(rank, world, port, fault, q):
+    """One step in which rank 1 alone fails (fault = "route": its routing raises, as for a read with a byte outside ACGTN;
+    "count": its counting raises; "oversize": rank 0 receives more keys than it was sized for).  Every rank must come
+    back from process_step with an exception - none may be left waiting in a collective."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
+
+        class Faulty(CheckerEngine):
+            def route(self, keys, n_shards):
+                if fault == "route" and rank == 1:
+                    raise ValueError("sequence byte outside ACGTN")
+                return super().route(keys, n_shards)
+
+            def count(self, recv_keys):
+                if fault == "count" and rank == 1:
+                    raise MemoryError("table shard cannot grow")
+                return super().count(recv_keys)
+
+        eng = Faulty(9, 3, False)
+        if fault == "oversize" and rank == 0:
+            eng.cap = 10
+        sn = ShardedNormaliser(eng, check_elems=0)
+        seq, off = concat(make_reads(rank, 30, 9, 60))
+        try:
+            sn.process_step(torch.from_numpy(seq), torch.from_numpy(off), len(off) - 1, len(seq))
+            q.put((rank, "returned"))
+        except Exception as e:
+            q.put((rank, type(e).__name__ + ": " + str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fault", ["route", "count", "oversize"])
+def test_a_rank_that_fails_stops_every_rank(fault):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=failing_worker, args=(r, world, port, fault, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))   # a rank left waiting in a collective would time out here
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    culprit = 0 if fault == "oversize" else 1
+    assert {"route": "ValueError", "count": "MemoryError", "oversize": "RuntimeError: received"}[fault] in got[culprit]
+    assert "another rank stopped this step" in got[1 - culprit]
