@@ -246,10 +246,24 @@ static void unmap_file(struct mapped *m)
 
 static const uint8_t base_class[256] = {['A'] = 1, ['C'] = 1, ['G'] = 1, ['T'] = 1, ['N'] = 2}; /* valid_dna after N->A, ref:1144-1158, 1406 */
 
+/* Eight bytes at a time: every byte must be one of A C G T N.  (x ^ c) has a zero byte exactly where x holds c; the
+ * zero-byte test used here has no carries between bytes, so a mark (0x80) stands for that byte alone. */
+static inline uint64_t bytes_equal(uint64_t x, uint8_t c)
+{
+    const uint64_t v = x ^ (0x0101010101010101ULL * c), m = 0x7f7f7f7f7f7f7f7fULL;
+    return ~(((v & m) + m) | v | m);
+}
 static bool valid_bases(const char *s, uint32_t n)
 {
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, s + i, 8);
+        const uint64_t hit = bytes_equal(x, 'A') | bytes_equal(x, 'C') | bytes_equal(x, 'G') | bytes_equal(x, 'T') | bytes_equal(x, 'N');
+        if (hit != 0x8080808080808080ULL) return false;
+    }
     uint8_t ok = 1;
-    for (uint32_t i = 0; i < n; i++) ok &= (uint8_t)(base_class[(uint8_t)s[i]] != 0);
+    for (; i < n; i++) ok &= (uint8_t)(base_class[(uint8_t)s[i]] != 0);
     return ok;
 }
 
@@ -296,30 +310,38 @@ struct findex {
     uint32_t *nl;
     size_t n_nl, cap_nl;
     size_t n_lines; /* newline-terminated lines, plus the unterminated last line of the file (ref:394-409) */
-    size_t cnt[MAX_THREADS + 1];
 };
 static inline size_t line_start(const struct findex *fi, size_t g) { return g ? (size_t)fi->nl[g - 1] + 1 : 0; }
 static inline size_t line_end(const struct findex *fi, size_t g) { return g < fi->n_nl ? (size_t)fi->nl[g] : fi->size; }
 
-static void index_count(int tid, int nt, void *arg)
+/* One scan per thread over its share of the bytes: newline offsets go straight into the thread's own stretch of nl[]
+ * (room for one newline every `min_line` bytes would be wasteful: the stretch is sized from the density seen so far and
+ * the scan falls back to counting if it runs out), then the stretches are closed up in place. */
+struct index_part { size_t at, n, cap; bool overflow; };
+static struct index_part ipart[MAX_THREADS];
+
+static void index_scan(int tid, int nt, void *arg)
 {
     struct findex *fi = arg;
     const char *p = fi->base + fi->size * (size_t)tid / (size_t)nt, *e = fi->base + fi->size * (size_t)(tid + 1) / (size_t)nt;
+    struct index_part *ip = &ipart[tid];
+    uint32_t *out = fi->nl + ip->at;
     size_t c = 0;
     while (p < e) {
         const char *q = memchr(p, '\n', (size_t)(e - p));
         if (!q) break;
+        if (c < ip->cap) out[c] = (uint32_t)(q - fi->base);
         c++;
         p = q + 1;
     }
-    fi->cnt[tid] = c;
+    ip->n = c;
+    ip->overflow = c > ip->cap;
 }
 static void index_fill(int tid, int nt, void *arg)
 {
     struct findex *fi = arg;
     const char *p = fi->base + fi->size * (size_t)tid / (size_t)nt, *e = fi->base + fi->size * (size_t)(tid + 1) / (size_t)nt;
-    size_t at = 0;
-    for (int t = 0; t < tid; t++) at += fi->cnt[t];
+    size_t at = ipart[tid].at;
     while (p < e) {
         const char *q = memchr(p, '\n', (size_t)(e - p));
         if (!q) break;
@@ -331,18 +353,42 @@ static void build_index(struct findex *fi, const char *base, size_t size, bool a
 {
     fi->base = base;
     fi->size = size;
-    parallel_run(index_count, fi);
-    size_t n = 0;
-    for (int t = 0; t < n_threads; t++) n += fi->cnt[t];
-    if (n > fi->cap_nl) {
-        free(fi->nl);
-        fi->cap_nl = n + n / 8 + 1024;
-        fi->nl = malloc(fi->cap_nl * sizeof(uint32_t));
-        if (!fi->nl) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+    /* lines of FASTQ / FASTA records are rarely shorter than 20 bytes on average; the density of the last window refines it */
+    static double bytes_per_line = 20.0;
+    {
+        const size_t per = (size_t)((double)(size / (size_t)n_threads + 1) / bytes_per_line * 1.1) + 64;
+        if (per * (size_t)n_threads > fi->cap_nl) {
+            free(fi->nl);
+            fi->cap_nl = per * (size_t)n_threads;
+            fi->nl = malloc(fi->cap_nl * sizeof(uint32_t));
+            if (!fi->nl) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+        }
+        for (int t = 0; t < n_threads; t++) ipart[t] = (struct index_part){(size_t)t * per, 0, per, false};
+        parallel_run(index_scan, fi);
+        size_t n = 0;
+        bool overflow = false;
+        for (int t = 0; t < n_threads; t++) { n += ipart[t].n; overflow |= ipart[t].overflow; }
+        if (overflow) { /* denser than expected: the counts are known now, so the second scan fits exactly */
+            if (n > fi->cap_nl) {
+                free(fi->nl);
+                fi->cap_nl = n + n / 8 + 1024;
+                fi->nl = malloc(fi->cap_nl * sizeof(uint32_t));
+                if (!fi->nl) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+            }
+            size_t at = 0;
+            for (int t = 0; t < n_threads; t++) { ipart[t].at = at; at += ipart[t].n; }
+            parallel_run(index_fill, fi);
+        } else { /* close the gaps between the threads' stretches (thread 0's is in place already) */
+            size_t at = ipart[0].n;
+            for (int t = 1; t < n_threads; t++) {
+                memmove(fi->nl + at, fi->nl + ipart[t].at, ipart[t].n * sizeof(uint32_t));
+                at += ipart[t].n;
+            }
+        }
+        fi->n_nl = n;
+        if (n > 1024) bytes_per_line = (double)size / (double)n;
     }
-    fi->n_nl = n;
-    parallel_run(index_fill, fi);
-    fi->n_lines = n + (at_eof && size > 0 && base[size - 1] != '\n' ? 1 : 0);
+    fi->n_lines = fi->n_nl + (at_eof && size > 0 && base[size - 1] != '\n' ? 1 : 0);
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
@@ -373,15 +419,18 @@ struct plan {
     uint32_t K;
     /* sizing pass, per thread */
     size_t t_units[MAX_THREADS], t_bases[MAX_THREADS], t_bad[MAX_THREADS];
+    size_t t_seedable[2][MAX_THREADS], t_unused[MAX_THREADS]; /* records whose fwd / rev read is longer than k; records not counted */
     int t_bad_rev[MAX_THREADS], long_line;
-    /* formatting pass, per thread */
-    char *obuf[2][MAX_THREADS];
-    size_t ocap[2][MAX_THREADS], olen[2][MAX_THREADS], t_printed[MAX_THREADS];
+    /* formatting pass, per thread; two sets of buffers take turns, so that one window's kept records can still be on
+     * their way to the files while the next window's are formatted */
+    int set;
+    char *obuf[2][2][MAX_THREADS];
+    size_t ocap[2][2][MAX_THREADS], olen[2][2][MAX_THREADS], t_printed[MAX_THREADS];
 };
 
 static struct batch B;
 static struct plan P;
-static struct window WIN[2], *W = &WIN[0]; /* W: the window the running phase works on */
+static struct window WIN[3], *W = &WIN[0]; /* W: the window the running phase works on (WIN[2]: spare for a seeding pass in mid-loop) */
 
 /* NKML_TIMING=1: wall time of each phase of the host pipeline on stderr at exit */
 static int timing_on;
@@ -397,6 +446,16 @@ static inline double now_s(void)
 static nkml_ctx *ctx;     /* one device ... */
 static nkml_multi *mctx;  /* ... or one table over several (NKML_DEVICES): exactly one of the two is set */
 static int out_fd[2] = {-1, -1};  /* forward / reverse output files */
+static char *out_name[2];
+/* Seeding of the first file (pair) folded into the record loop: a record that is going to be counted needs no seeding
+ * (its k-mers enter the table anyway, and a key inserted with count 0 changes nothing else), so only the reads the
+ * loop drops - a mate longer than k whose partner is too short - are seeded, when their window comes up.  The
+ * reference's own seeding pass over that file (ref:2242-2250) is only run for real if the loop meets a record the
+ * reference would have died on during seeding, to die the same way (before any output file exists). */
+static bool lazy_seed;
+static size_t lazy_limit, lazy_seen[2];      /* records with a read longer than k seen so far in the fwd / rev file */
+static bool unlink_outputs_on_seed_fatal;
+static void seed_file(const char *name, int limit);
 static off_t out_off[2];          /* bytes written so far */
 static struct totals tot;
 
@@ -425,7 +484,7 @@ static void batch_alloc(uint32_t cap_reads, uint64_t cap_bases)
     B.cap_bases = cap_bases;
     int rc = eng_host_staging(&B.seq, &B.offsets);
     if (rc != NKML_OK) die_nkml("staging", rc);
-    for (int w = 0; w < 2; w++) {
+    for (int w = 0; w < 3; w++) {
         WIN[w].rec = malloc((size_t)cap_reads * sizeof(uint32_t));
         WIN[w].high = malloc((size_t)cap_reads * sizeof(int32_t));
         WIN[w].total = malloc((size_t)cap_reads * sizeof(int32_t));
@@ -462,8 +521,9 @@ static void size_records(int tid, int nt, void *arg)
     (void)arg;
     size_t a, b;
     rec_range(W->n_rec, tid, nt, &a, &b);
-    size_t units = 0, bases = 0;
+    size_t units = 0, bases = 0, seedable_f = 0, seedable_r = 0, unused = 0;
     P.t_bad[tid] = SIZE_MAX;
+    P.t_seedable[0][tid] = P.t_seedable[1][tid] = P.t_unused[tid] = 0;
     for (size_t i = a; i < b; i++) {
         for (int l = 0; l < P.lines; l++) {
             const size_t g = i * (size_t)P.lines + (size_t)l;
@@ -475,7 +535,9 @@ static void size_records(int tid, int nt, void *arg)
         const char *sr = P.paired ? seq_line(&W->R, P.lines, i, &lr) : NULL;
         const bool long_enough = lf >= P.K && (!P.paired || lr >= P.K);
         W->use[i] = long_enough;
-        if (!long_enough) continue; /* dropped without being counted anywhere, ref:1630-1631 */
+        seedable_f += lf > P.K;
+        seedable_r += P.paired && lr > P.K;
+        if (!long_enough) { unused++; continue; } /* dropped without being counted anywhere, ref:1630-1631 */
         if (lf > MAX_LINE || lr > MAX_LINE) continue; /* reported after the phase */
         if (!valid_bases(sf, lf)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 0; break; }
         if (P.paired && !valid_bases(sr, lr)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 1; break; }
@@ -484,6 +546,9 @@ static void size_records(int tid, int nt, void *arg)
     }
     P.t_units[tid] = units;
     P.t_bases[tid] = bases;
+    P.t_seedable[0][tid] = seedable_f;
+    P.t_seedable[1][tid] = seedable_r;
+    P.t_unused[tid] = unused;
 }
 
 /* Phase 2: sequence lines into the staging area, in record order */
@@ -540,12 +605,17 @@ static char *put_record(char *o, const struct findex *fi, size_t i, int lines, b
         *o++ = '\n';
         return put_masked(o, fi->base + line_start(fi, g0 + 1), line_end(fi, g0 + 1) - line_start(fi, g0 + 1));
     }
-    for (int l = 0; l < lines; l++) {
-        const size_t a = line_start(fi, g0 + (size_t)l), n = line_end(fi, g0 + (size_t)l) - a;
-        if (l == 1) o = put_masked(o, fi->base + a, n);
-        else { memcpy(o, fi->base + a, n); o[n] = '\n'; o += n + 1; }
-    }
-    return o;
+    /* the stored lines, each followed by a newline: in the input they lie back to back with their newlines, so the
+     * record is one copy (plus the newline an unterminated last line of the file lacks), and the sequence line is
+     * N-masked where it landed */
+    const size_t a = line_start(fi, g0), e = line_end(fi, g0 + (size_t)lines - 1);
+    const size_t sa = line_start(fi, g0 + 1) - a, sn = line_end(fi, g0 + 1) - line_start(fi, g0 + 1);
+    memcpy(o, fi->base + a, e - a);
+    if (memchr(o + sa, 'N', sn))
+        for (size_t j = 0; j < sn; j++)
+            if (o[sa + j] == 'N') o[sa + j] = 'A';
+    o[e - a] = '\n';
+    return o + (e - a) + 1;
 }
 
 static inline bool keep_unit(uint32_t u)
@@ -560,7 +630,8 @@ static void format_records(int tid, int nt, void *arg)
     (void)arg;
     size_t a, b;
     rec_range(W->n_units, tid, nt, &a, &b);
-    P.olen[0][tid] = P.olen[1][tid] = 0;
+    const int set = P.set;
+    P.olen[set][0][tid] = P.olen[set][1][tid] = 0;
     P.t_printed[tid] = 0;
     if (a == b) return;
     /* ref:1995-1999: the single-end FASTQ->FASTA branch builds the record and never writes it */
@@ -570,14 +641,14 @@ static void format_records(int tid, int nt, void *arg)
         const struct findex *fi = f == 0 ? &W->F : &W->R;
         const size_t first = (size_t)W->rec[a] * (size_t)P.lines, last = (size_t)W->rec[b - 1] * (size_t)P.lines + (size_t)P.lines - 1;
         const size_t need = line_end(fi, last) - line_start(fi, first) + 4 * (b - a) + 64;
-        if (need > P.ocap[f][tid]) {
-            free(P.obuf[f][tid]);
-            P.ocap[f][tid] = need + need / 4;
-            P.obuf[f][tid] = malloc(P.ocap[f][tid]);
-            if (!P.obuf[f][tid]) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
+        if (need > P.ocap[set][f][tid]) {
+            free(P.obuf[set][f][tid]);
+            P.ocap[set][f][tid] = need + need / 4;
+            P.obuf[set][f][tid] = malloc(P.ocap[set][f][tid]);
+            if (!P.obuf[set][f][tid]) { fprintf(stderr, "Memory allocation failed\n"); exit(EXIT_FAILURE); }
         }
     }
-    char *of = P.obuf[0][tid], *orv = P.obuf[1][tid];
+    char *of = P.obuf[set][0][tid], *orv = P.obuf[set][1][tid];
     size_t printed = 0;
     for (size_t u = a; u < b; u++) {
         if (!keep_unit((uint32_t)u)) continue;
@@ -585,27 +656,119 @@ static void format_records(int tid, int nt, void *arg)
         if (write_f) of = put_record(of, &W->F, W->rec[u], P.lines, P.to_fasta, true);
         if (write_r) orv = put_record(orv, &W->R, W->rec[u], P.lines, P.to_fasta, false);
     }
-    P.olen[0][tid] = write_f ? (size_t)(of - P.obuf[0][tid]) : 0;
-    P.olen[1][tid] = write_r ? (size_t)(orv - P.obuf[1][tid]) : 0;
+    P.olen[set][0][tid] = write_f ? (size_t)(of - P.obuf[set][0][tid]) : 0;
+    P.olen[set][1][tid] = write_r ? (size_t)(orv - P.obuf[set][1][tid]) : 0;
     P.t_printed[tid] = printed;
 }
 
-/* Phase 4: every thread writes its buffer at its place in the output files (input order = thread order) */
-static void write_records(int tid, int nt, void *arg)
+/* Phase 4: the buffers go to the output files, in thread order (= input order), by one writer thread per file.  Buffered
+ * writes to one file take the file's lock one after the other whatever the number of threads that issue them, so one
+ * thread per file does as well as sixteen - and as a thread of its own it works while the record loop is already
+ * indexing, sizing and staging the next window. */
+struct writer {
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int f;              /* 0 forward, 1 reverse */
+    int job_set;        /* set of buffers waiting to be written, -1 none */
+    int busy_set;       /* set being written, -1 none */
+    off_t job_off;      /* file offset of the waiting job */
+    int job_threads;
+    bool quit, started, inited;
+};
+static struct writer WR[2];
+
+static void *writer_main(void *arg)
 {
-    (void)arg;
-    (void)nt;
-    for (int f = 0; f < 2; f++) {
-        size_t n = P.olen[f][tid];
-        if (!n || out_fd[f] < 0) continue;
-        off_t at = out_off[f];
-        for (int t = 0; t < tid; t++) at += (off_t)P.olen[f][t];
-        const char *p = P.obuf[f][tid];
-        while (n) {
-            ssize_t w = pwrite(out_fd[f], p, n, at);
-            if (w < 0) { perror("Error writing output"); exit(EXIT_FAILURE); }
-            p += w; n -= (size_t)w; at += w;
+    struct writer *w = arg;
+    pthread_mutex_lock(&w->mu);
+    for (;;) {
+        while (w->job_set < 0 && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+        if (w->job_set < 0) break;
+        const int set = w->job_set, nt = w->job_threads;
+        off_t at = w->job_off;
+        w->busy_set = set;
+        w->job_set = -1;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        for (int t = 0; t < nt; t++) {
+            size_t n = P.olen[set][w->f][t];
+            const char *p = P.obuf[set][w->f][t];
+            while (n) {
+                ssize_t k = pwrite(out_fd[w->f], p, n, at);
+                if (k < 0) { perror("Error writing output"); exit(EXIT_FAILURE); }
+                p += k; n -= (size_t)k; at += k;
+            }
         }
+        pthread_mutex_lock(&w->mu);
+        w->busy_set = -1;
+        pthread_cond_broadcast(&w->cv);
+    }
+    pthread_mutex_unlock(&w->mu);
+    return NULL;
+}
+
+static void writers_start(void)
+{
+    for (int f = 0; f < 2; f++) {
+        struct writer *w = &WR[f];
+        if (out_fd[f] < 0 || w->started) continue;
+        if (!w->inited) {
+            pthread_mutex_init(&w->mu, NULL);
+            pthread_cond_init(&w->cv, NULL);
+            w->inited = true;
+        }
+        w->f = f;
+        w->job_set = w->busy_set = -1;
+        w->quit = false;
+        if (pthread_create(&w->th, NULL, writer_main, w) != 0) { perror("pthread_create"); exit(EXIT_FAILURE); }
+        w->started = true;
+    }
+}
+
+/* until neither writer holds buffers of `set` any more (set < 0: any set) */
+static void writers_wait(int set)
+{
+    for (int f = 0; f < 2; f++) {
+        struct writer *w = &WR[f];
+        if (!w->started) continue;
+        pthread_mutex_lock(&w->mu);
+        while ((w->job_set >= 0 && (set < 0 || w->job_set == set)) || (w->busy_set >= 0 && (set < 0 || w->busy_set == set)))
+            pthread_cond_wait(&w->cv, &w->mu);
+        pthread_mutex_unlock(&w->mu);
+    }
+}
+
+static void writers_post(int set)
+{
+    for (int f = 0; f < 2; f++) {
+        struct writer *w = &WR[f];
+        size_t total = 0;
+        for (int t = 0; t < n_threads; t++) total += P.olen[set][f][t];
+        if (!w->started || total == 0) continue;
+        pthread_mutex_lock(&w->mu);
+        while (w->job_set >= 0) pthread_cond_wait(&w->cv, &w->mu); /* the mailbox holds one job */
+        w->job_set = set;
+        w->job_off = out_off[f];
+        w->job_threads = n_threads;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        out_off[f] += (off_t)total;
+    }
+}
+
+static void writers_stop(void)
+{
+    writers_wait(-1);
+    for (int f = 0; f < 2; f++) {
+        struct writer *w = &WR[f];
+        if (!w->started) continue;
+        pthread_mutex_lock(&w->mu);
+        w->quit = true;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        pthread_join(w->th, NULL);
+        w->started = false;
     }
 }
 
@@ -634,14 +797,10 @@ static void finish_window(void)
 static void write_window(void)
 {
     if (W->n_units == 0) return;
+    TIMED(5, writers_wait(P.set)); /* the window before the last one has left these buffers */
     TIMED(4, parallel_run(format_records, NULL));
-    TIMED(5, {
-        parallel_run(write_records, NULL);
-        for (int t = 0; t < n_threads; t++) {
-            out_off[0] += (off_t)P.olen[0][t];
-            out_off[1] += (off_t)P.olen[1][t];
-        }
-    });
+    writers_post(P.set);
+    P.set ^= 1;
     if (cfg.debug > 1) {
         for (uint32_t u = 0; u < W->n_units; u++) {
             const bool keep = keep_unit(u);
@@ -726,6 +885,62 @@ static bool size_window(const struct mapped *fwd, const struct mapped *rev, size
     return true;
 }
 
+static inline bool record_terminated(const struct findex *fi, int lines, size_t i)
+{
+    return i * (size_t)lines + (size_t)lines - 1 < fi->n_nl; /* the seeding pass only sees newline-terminated lines (ref:1322-1373) */
+}
+
+/* after sizing: does this window hold a read that the seeding pass would have inserted and the loop will not count? */
+static bool lazy_window_needs_seeding(void)
+{
+    size_t unused = 0;
+    for (int t = 0; t < n_threads; t++) unused += P.t_unused[t];
+    const bool open = lazy_seen[0] < lazy_limit || (P.paired && lazy_seen[1] < lazy_limit);
+    if (unused && open) return true;
+    for (int t = 0; t < n_threads; t++) { lazy_seen[0] += P.t_seedable[0][t]; lazy_seen[1] += P.t_seedable[1][t]; }
+    return false;
+}
+
+/* Seeds those reads (sequence_to_hash_zero, ref:1501-1537): records in order, each file's first lazy_limit reads longer
+ * than k count towards its limit, the ones whose record the loop drops are inserted.  Uses the staging area, which
+ * is free at this point. */
+static void lazy_seed_window(void)
+{
+    uint32_t n = 0;
+    uint64_t at = 0;
+    for (size_t i = 0; i < W->n_rec; i++) {
+        for (int f = 0; f < (P.paired ? 2 : 1); f++) {
+            const struct findex *fi = f == 0 ? &W->F : &W->R;
+            uint32_t len;
+            const char *sq = seq_line(fi, P.lines, i, &len);
+            if (len <= P.K || len > MAX_LINE || !record_terminated(fi, P.lines, i)) continue;
+            if (lazy_seen[f]++ >= lazy_limit || W->use[i]) continue;
+            if (!valid_bases(sq, len)) { /* the reference's seeding pass dies here: let it */
+                writers_stop();
+                unlink_outputs_on_seed_fatal = true;
+                W = &WIN[2];
+                seed_file(cfg.fwd[0], (int)lazy_limit);
+                if (cfg.n_rev > 0) seed_file(cfg.rev[0], (int)lazy_limit);
+                fprintf(stderr, "internal error: the seeding pass did not stop at the invalid read\n");
+                exit(EXIT_FAILURE);
+            }
+            if (n == B.cap_reads || at + len > B.cap_bases) {
+                int rc = eng_seed(B.seq, B.offsets, n);
+                if (rc != NKML_OK) die_nkml("seed", rc);
+                n = 0;
+                at = 0;
+            }
+            memcpy(B.seq + at, sq, len);
+            at += len;
+            B.offsets[++n] = at;
+        }
+    }
+    if (n) {
+        int rc = eng_seed(B.seq, B.offsets, n);
+        if (rc != NKML_OK) die_nkml("seed", rc);
+    }
+}
+
 /* The record loop of process_thread_chunk_paired / _single (ref:1568-1770, 1921-2111) for one file (pair):
  * window after window, each a whole number of records that fits one GPU batch.  While the GPU counts window i the
  * host indexes and sizes window i+1, and once window i+1 has been handed over, formats and writes window i. */
@@ -744,18 +959,39 @@ static void process_files(const struct mapped *fwd, const struct mapped *rev)
         size_t bad = SIZE_MAX;
         int bad_rev = 0;
         const bool more = size_window(fwd, rev, &pos_f, &pos_r, &bytes_per_rec, &bad, &bad_rev);
+        bool prev_done = false;
         if (more) {
             /* the staging area is the library's: the previous window's copy to the device has to be over */
             if (prev) { int rc = eng_wait_staged(); if (rc != NKML_OK) die_nkml("wait", rc); }
+            if (lazy_seed && lazy_window_needs_seeding()) {
+                if (prev) { W = prev; finish_window(); W = cur; prev_done = true; }
+                TIMED(6, lazy_seed_window());
+            }
             TIMED(2, parallel_run(stage_records, NULL));
         }
-        if (prev) { W = prev; finish_window(); W = cur; }
+        if (prev && !prev_done) { W = prev; finish_window(); W = cur; }
         if (more) submit_window();
         if (prev) { W = prev; write_window(); W = cur; }
         if (!more) break;
         if (bad != SIZE_MAX) { /* everything before the bad record is counted and written, then the reference's exit */
             finish_window();
+            if (lazy_seed) {
+                /* would the reference's seeding pass have met it first?  Run that pass now: it ends the run like the reference
+                 * (no output files yet) if so, and comes back if the record lies beyond the seeded prefix */
+                struct window *keep = W;
+                const struct plan keep_plan = P;
+                writers_stop();
+                unlink_outputs_on_seed_fatal = true;
+                W = &WIN[2];
+                seed_file(cfg.fwd[0], (int)lazy_limit);
+                if (cfg.n_rev > 0) seed_file(cfg.rev[0], (int)lazy_limit);
+                unlink_outputs_on_seed_fatal = false;
+                W = keep;
+                P = keep_plan;
+                writers_start();
+            }
             write_window();
+            writers_stop();
             uint32_t len;
             const char *sq = seq_line(bad_rev ? &W->R : &W->F, P.lines, bad, &len);
             fatal_sequence(bad_rev ? "REV" : "FWD", sq, len);
@@ -825,6 +1061,9 @@ static void seed_file(const char *name, int limit)
             if (bad != SIZE_MAX) { /* a record the reference would have stopped at before reaching the limit */
                 uint32_t len;
                 const char *sq = seq_line(&W->F, P.lines, bad, &len);
+                if (unlink_outputs_on_seed_fatal) /* the reference dies here before it has created its output files */
+                    for (int f = 0; f < 2; f++)
+                        if (out_name[f]) unlink(out_name[f]);
                 fatal_sequence("FWD", sq, len);
                 exit(EXIT_FAILURE);
             }
@@ -955,8 +1194,12 @@ int main(int argc, char **argv)
     /* seeding pass over every input file, before any counting: ref:2242-2250 */
     int seed_n = 1 + (int)(SEED_RECORDS / cfg.n_fwd);
     if (!getenv("NKML_NO_SEED")) {
+        /* the first file (pair) is seeded from within the record loop (see lazy_seed) unless the seeding pass itself is
+         * on show: --verbose reports it, --print dumps the seeded table, NKML_EAGER_SEED=1 asks for it */
+        lazy_seed = !cfg.verbose && !cfg.doprint && !getenv("NKML_EAGER_SEED");
+        lazy_limit = (size_t)seed_n;
         TIMED(6, {
-            for (int i = 0; i < cfg.n_fwd; i++) {
+            for (int i = lazy_seed ? 1 : 0; i < cfg.n_fwd; i++) {
                 seed_file(cfg.fwd[i], seed_n);
                 if (i < cfg.n_rev) seed_file(cfg.rev[i], seed_n);
             }
@@ -965,15 +1208,18 @@ int main(int argc, char **argv)
     if (cfg.doprint) print_table("_seeds", -1);
 
     char *name_f = output_name("output_forward", cfg.ksize, cfg.depth, 0, "fastq"); /* ref:2286: always .fastq */
+    out_name[0] = name_f;
     out_fd[0] = open(name_f, O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (out_fd[0] < 0) { fprintf(stderr, "Error opening file to write: %s\n", name_f); return EXIT_FAILURE; }
     char *name_r = NULL;
     if (cfg.n_rev != 0) { /* ref:2294 */
         name_r = output_name("output_reverse", cfg.ksize, cfg.depth, 0, "fastq");
+        out_name[1] = name_r;
         out_fd[1] = open(name_r, O_WRONLY | O_CREAT | O_TRUNC, 0666);
         if (out_fd[1] < 0) { fprintf(stderr, "Error opening file to write: %s\n", name_r); return EXIT_FAILURE; }
     }
 
+    writers_start();
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     size_t max_unique = 0;
@@ -1001,6 +1247,7 @@ int main(int argc, char **argv)
         clock_gettime(CLOCK_MONOTONIC, &f0);
         size_t before = tot.processed;
         process_files(&mf, paired ? &mr : NULL);
+        lazy_seed = false; /* only the first file (pair) was left to the loop */
         clock_gettime(CLOCK_MONOTONIC, &f1);
         nkml_stats st;
         if ((rc = eng_stats(&st)) != NKML_OK) die_nkml("stats", rc);
@@ -1014,6 +1261,7 @@ int main(int argc, char **argv)
         unmap_file(&mf);
         if (paired) unmap_file(&mr);
     }
+    TIMED(5, writers_stop());
     close(out_fd[0]);
     if (out_fd[1] >= 0) close(out_fd[1]);
     if (cfg.doprint) print_table("", 0);
