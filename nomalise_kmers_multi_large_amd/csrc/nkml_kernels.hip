@@ -1156,6 +1156,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 }
 
 #include "nkml_partition.inc"
+#include "nkml_hashpart.inc"
 
 // table dump helpers
 __global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ extra, uint64_t cap, unsigned long long *codes,
@@ -1221,6 +1222,13 @@ struct nkml_ctx {
     uint32_t *pt_sposA, *pt_sposB; // sorted positions, 12 bits each: what the forward passes leave for the reverse passes
     uint8_t *pt_flagsA, *pt_flagsB;
     uint64_t pt_tiles_a, pt_tiles_b; // strides of the histograms (tiles of the largest batch)
+    // the same for the hashed table (k > 16): 8-byte slots grouped in 2^16 buckets, 64-bit hashes through the passes
+    bool hashpart;
+    unsigned long long *hp_table, *hp_keysA, *hp_keysB;
+    uint32_t *hp_done;       // per bucket workgroup: its part of the current batch is committed
+    int hp_log2_bucket;      // slots per bucket = 2^hp_log2_bucket; capacity = 2^(16 + hp_log2_bucket)
+    int hp_log2_local_max;   // slots one bucket workgroup holds in LDS at most (2^this)
+    uint64_t hp_unique_before; // stored k-mers when the last batch began (what a batch adds is the best guess for the next one)
     uint64_t pt_timed_keys;
     bool pt_timing_pending;
     double pt_stage_ms;
@@ -1309,6 +1317,9 @@ uint64_t default_hashed_capacity(int memory_gb)
     return cap;
 }
 
+constexpr int HP_MAX_LOG2_BUCKET = 16;                                        // 2^32 slots = 32 GiB of table
+constexpr uint32_t HP_MAX_GRID = 65536u << 6;                                 // most bucket workgroups of one launch
+
 // bytes of the partitioned path's table: one entry per k-mer, at least one bucket
 uint64_t pt_table_bytes(const nkml_ctx *c)
 {
@@ -1319,15 +1330,40 @@ uint64_t pt_table_bytes(const nkml_ctx *c)
 int alloc_table(nkml_ctx *c)
 {
     if (c->partitioned) {
-        c->capacity = 1ull << (2 * c->cfg.ksize);
-        HIPCHK(c, hipMalloc(&c->pt_table, pt_table_bytes(c)));
         const uint64_t npos = c->max_words * 16;
+        if (c->hashpart) {
+            c->capacity = default_hashed_capacity(c->cfg.memory_gb);
+            c->hp_log2_bucket = 0;
+            while ((65536ull << c->hp_log2_bucket) < c->capacity) c->hp_log2_bucket++;
+            c->hp_log2_local_max = HB_MAX_SLOTS_LOG2;
+            if (const char *e = getenv("NKML_HP_LOG2_LOCAL")) { // tuning aid
+                const int v = atoi(e);
+                if (v >= 6 && v <= HB_MAX_SLOTS_LOG2) c->hp_log2_local_max = v;
+            }
+            if (const char *e = getenv("NKML_HP_LOG2_BUCKET")) { // test aid: a tiny table, so that small inputs make it grow
+                const int v = atoi(e);
+                if (v >= 2 && v <= HP_MAX_LOG2_BUCKET) { c->hp_log2_bucket = v; c->capacity = 65536ull << v; } // at least one set of slots
+            }
+            HIPCHK(c, hipMalloc(&c->hp_table, c->capacity * sizeof(unsigned long long)));
+            HIPCHK(c, hipMalloc(&c->hp_done, HP_MAX_GRID * sizeof(uint32_t)));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_count_bucket), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(HB_MAX_SLOTS * 12)));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HB_MAX_SLOTS * 8)));
+        } else {
+            c->capacity = 1ull << (2 * c->cfg.ksize);
+            HIPCHK(c, hipMalloc(&c->pt_table, pt_table_bytes(c)));
+        }
         c->pt_tiles_a = (npos + PT_TILE - 1) / PT_TILE;
         c->pt_tiles_b = c->pt_tiles_a + 256 + 1;
         const uint64_t na = (c->pt_tiles_b + 1) * PT_TILE;
-        HIPCHK(c, hipMalloc(&c->pt_keysA, na * sizeof(uint32_t)));
+        if (c->hashpart) {
+            HIPCHK(c, hipMalloc(&c->hp_keysA, na * sizeof(unsigned long long)));
+            HIPCHK(c, hipMalloc(&c->hp_keysB, npos * sizeof(unsigned long long)));
+        } else {
+            HIPCHK(c, hipMalloc(&c->pt_keysA, na * sizeof(uint32_t)));
+            HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
+        }
         HIPCHK(c, hipMalloc(&c->pt_flagsA, na));
-        HIPCHK(c, hipMalloc(&c->pt_keysB, npos * sizeof(uint16_t)));
         HIPCHK(c, hipMalloc(&c->pt_flagsB, npos));
         HIPCHK(c, hipMalloc(&c->pt_sposA, c->pt_tiles_a * PT_TILE / 8 * 3 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_sposB, na / 8 * 3 * sizeof(uint32_t)));
@@ -1338,7 +1374,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_scanB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_startB, 260 * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->pt_tally, ((c->capacity >> PT_LOWBITS) + 1) * sizeof(uint4)));
+        HIPCHK(c, hipMalloc(&c->pt_tally, (c->hashpart ? (uint64_t)HP_MAX_GRID : (c->capacity >> PT_LOWBITS) + 1) * sizeof(uint4)));
         HIPCHK(c, hipMalloc(&c->pt_totals, 256 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_chunks, 256 * ((c->pt_tiles_b + 1 + PT_CH - 1) / PT_CH + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_pt_count_bucket_big<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -1372,7 +1408,9 @@ hipError_t zero_device(void *p, uint64_t bytes, hipStream_t stream)
 
 int clear_table(nkml_ctx *c)
 {
-    if (c->partitioned) {
+    if (c->hashpart) {
+        HIPCHK(c, zero_device(c->hp_table, c->capacity * sizeof(unsigned long long), c->stream));
+    } else if (c->partitioned) {
         HIPCHK(c, zero_device(c->pt_table, pt_table_bytes(c), c->stream));
     } else if (c->direct) {
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
@@ -1678,9 +1716,13 @@ int collect_partition_timing(nkml_ctx *c);
 
 // d_keys == nullptr: the keys of the first pass are recomputed from the context's packed words (n_bases of them
 // prepared); d_flags == nullptr: the result is the context's word flags (one word per 16 positions).
-int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
+int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding);
+
+int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
 {
     if (n == 0) return NKML_OK;
+    if (c->hashpart) return run_count_hashpart(c, static_cast<const unsigned long long *>(d_keys_any), n, n_bases, d_flags, seeding);
+    const uint32_t *d_keys = static_cast<const uint32_t *>(d_keys_any);
     if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
     if (profile && c->pt_timing_pending) { // the events are about to be recorded again: read the last batch's first
@@ -1756,6 +1798,153 @@ int run_count_partitioned(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint6
 #ifdef PB_STAMP
     hipLaunchKernelGGL(k_pt_stamp_print, 1, 1, 0, c->stream, (uint32_t)buckets);
 #endif
+    if (profile) {
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->pt_timed_keys = n;
+        c->pt_timing_pending = true;
+    }
+    return NKML_OK;
+}
+
+// Doubles the hashed partitioned table (every bucket gets twice the slots).  Waits for the device: the old table is
+// freed afterwards.  remap: a batch is under way, its per-workgroup "done" marks and tallies follow the slots.
+__global__ void __launch_bounds__(256) k_hp_remap_done(const uint32_t *__restrict__ done_old, const uint4 *__restrict__ tally_old, uint32_t n_old,
+                                                       uint32_t *__restrict__ done_new, uint4 *__restrict__ tally_new)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_old) return;
+    // workgroup i's sub-range of slots becomes the two sub-ranges 2i and 2i + 1
+    done_new[2 * i] = done_new[2 * i + 1] = done_old[i];
+    tally_new[2 * i] = done_old[i] ? tally_old[i] : make_uint4(0u, 0u, 0u, 0u);
+    tally_new[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int hp_grow(nkml_ctx *c, bool batch_under_way)
+{
+    if (c->hp_log2_bucket + 1 > HP_MAX_LOG2_BUCKET || (c->hp_log2_bucket + 1 > c->hp_log2_local_max && (65536ull << (c->hp_log2_bucket + 1 - c->hp_log2_local_max)) > HP_MAX_GRID))
+        return fail(c, NKML_E_NOMEM, "hashed table cannot grow beyond 2^%d slots", 16 + c->hp_log2_bucket);
+    const int lmax = c->hp_log2_local_max;
+    const HpGeom og = {c->hp_log2_bucket, c->hp_log2_bucket < lmax ? c->hp_log2_bucket : lmax};
+    const HpGeom ng = {c->hp_log2_bucket + 1, c->hp_log2_bucket + 1 < lmax ? c->hp_log2_bucket + 1 : lmax};
+    const uint64_t ncap = c->capacity * 2;
+    unsigned long long *nt = nullptr;
+    HIPCHK(c, hipMalloc(&nt, ncap * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_hp_grow, 65536u << (ng.log2_bucket - ng.log2_local), HB_THREADS, ((size_t)8) << ng.log2_local, c->stream, c->hp_table, og, nt, ng,
+                       c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    if (batch_under_way && ng.log2_bucket > ng.log2_local) { // the number of workgroups per bucket doubles
+        const uint32_t n_old = 65536u << (og.log2_bucket - og.log2_local);
+        uint32_t *d2 = nullptr;
+        uint4 *t2 = nullptr;
+        HIPCHK(c, hipMalloc(&d2, (uint64_t)n_old * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&t2, (uint64_t)n_old * sizeof(uint4)));
+        HIPCHK(c, hipMemcpyAsync(d2, c->hp_done, (uint64_t)n_old * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(t2, c->pt_tally, (uint64_t)n_old * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_hp_remap_done, blocks_for(n_old), 256, 0, c->stream, d2, t2, n_old, c->hp_done, c->pt_tally);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(d2);
+        hipFree(t2);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(c->hp_table));
+    c->hp_table = nt;
+    c->capacity = ncap;
+    c->hp_log2_bucket++;
+    c->resizes++;
+    return NKML_OK;
+}
+
+// The hashed table's partitioned counting of one batch: histogram + two partition passes on the hashes' top 16 bits,
+// the bucket kernel (relaunched after a doubling of the table for the buckets that did not fit), two reverse passes.
+// Waits for the device once per batch, after the bucket kernel (whether every bucket fitted is only known there).
+int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
+{
+    if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
+    if (d_keys && (reinterpret_cast<uintptr_t>(d_keys) & 15u)) return fail(c, NKML_E_ARG, "the key array must be 16-byte aligned");
+    int rc;
+    // between batches: the table doubles while this batch, if it adds as many k-mers as the last one did, would take it
+    // beyond 75 % full (store_kmer grows at 80 %, normalise_kmers_multi_large.c:143, 933).  Every batch sweeps the whole
+    // table through LDS, so a table larger than needed costs bandwidth; one that turns out too small costs a relaunch.
+    {
+        const uint64_t now = c->h_ctr->unique, added = now > c->hp_unique_before ? now - c->hp_unique_before : 0;
+        while ((double)(now + added) >= 0.75 * (double)c->capacity && c->hp_log2_bucket < HP_MAX_LOG2_BUCKET) {
+            if (hp_grow(c, false) != NKML_OK) break; // no room for a larger table now: the bucket kernel will say if it is needed
+        }
+        c->hp_unique_before = now;
+    }
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
+    if (profile && c->pt_timing_pending && (rc = collect_partition_timing(c)) != NKML_OK) return rc;
+    const uint64_t ta = (n + PT_TILE - 1) / PT_TILE, tb = ta + 256 + 1, ra = ta + 1, rb = tb + 1;
+    const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
+    const uint32_t *n_a = c->pt_pad + 256;
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(uint32_t), c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    const uint64_t n_words = n / 16;
+    const int k = c->cfg.ksize;
+    uint32_t *spos_a = seeding ? nullptr : c->pt_sposA, *spos_b = seeding ? nullptr : c->pt_sposB;
+    if (d_keys)
+        hipLaunchKernelGGL((k_hp_hist<true>), (uint32_t)ta, 256, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, HP_SHIFT_A, c->pt_histA);
+    else if (c->cfg.canonical)
+        hipLaunchKernelGGL((k_hp_hist_words<true>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, c->pt_histA);
+    else
+        hipLaunchKernelGGL((k_hp_hist_words<false>), (uint32_t)ta, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, c->pt_histA);
+    hipLaunchKernelGGL(k_pt_colsum, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks);
+    hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, ca, c->pt_totals);
+    hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 1, c->pt_pad);
+    hipLaunchKernelGGL(k_pt_rowscan, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks, c->pt_pad, c->pt_scanA);
+    hipLaunchKernelGGL(k_hp_zero_gaps, 256, 256, 0, c->stream, c->pt_totals, c->pt_pad, c->hp_keysA);
+    const uint32_t ga = (uint32_t)((ta + 7) / 8 * 8), gb = (uint32_t)((tb + 7) / 8 * 8);
+    if (d_keys)
+        hipLaunchKernelGGL((k_hp_scatter<true>), ga, PT_THREADS, 0, c->stream, d_keys, n, (const uint32_t *)nullptr, HP_SHIFT_A, c->pt_scanA, c->hp_keysA, spos_a);
+    else if (c->cfg.canonical)
+        hipLaunchKernelGGL((k_hp_scatter_words<true>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, c->pt_scanA, c->hp_keysA, spos_a);
+    else
+        hipLaunchKernelGGL((k_hp_scatter_words<false>), ga, PT_THREADS, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, c->pt_scanA, c->hp_keysA, spos_a);
+    hipLaunchKernelGGL((k_hp_hist<false>), (uint32_t)tb, 256, 0, c->stream, c->hp_keysA, (uint64_t)0, n_a, HP_SHIFT_B, c->pt_histB);
+    hipLaunchKernelGGL(k_pt_colsum, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks);
+    hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, cb, c->pt_totals);
+    hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 0, c->pt_startB);
+    hipLaunchKernelGGL(k_pt_rowscan, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
+    hipLaunchKernelGGL((k_hp_scatter<false>), gb, PT_THREADS, 0, c->stream, c->hp_keysA, (uint64_t)0, n_a, HP_SHIFT_B, c->pt_scanB, c->hp_keysB, spos_b);
+    HIPCHK(c, hipGetLastError());
+    {
+        // room for one doubling of the workgroups inside this batch
+        const int ll = c->hp_log2_bucket < c->hp_log2_local_max ? c->hp_log2_bucket : c->hp_log2_local_max;
+        uint64_t marks = (uint64_t)131072 << (c->hp_log2_bucket - ll);
+        if (marks > HP_MAX_GRID) marks = HP_MAX_GRID;
+        HIPCHK(c, hipMemsetAsync(c->hp_done, 0, marks * sizeof(uint32_t), c->stream));
+    }
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    uint32_t grid = 0;
+    for (int attempt = 0;; attempt++) {
+        const HpGeom geo = {c->hp_log2_bucket, c->hp_log2_bucket < c->hp_log2_local_max ? c->hp_log2_bucket : c->hp_log2_local_max};
+        grid = 65536u << (geo.log2_bucket - geo.log2_local);
+        const size_t lds = ((size_t)12) << geo.log2_local;
+        hipLaunchKernelGGL(k_hp_count_bucket, grid, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_scanB, c->pt_pad, c->hp_table, geo,
+                           (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        if (profile && attempt == 0) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        if ((rc = fetch_counters(c)) != NKML_OK) return rc; // did every bucket fit?
+        if (!c->h_ctr->probe_overflow) break;
+        if (attempt >= HP_MAX_LOG2_BUCKET) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->probe_overflow, 0, sizeof(unsigned int), c->stream));
+        c->h_ctr->probe_overflow = 0;
+        if ((rc = hp_grow(c, true)) != NKML_OK) return rc;
+    }
+#ifdef HB_STAMP
+    hipLaunchKernelGGL(k_hb_stamp_print, 1, 1, 0, c->stream);
+#endif
+    hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, grid, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    if (!seeding) {
+        hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
+                           c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_pt_ungather, ga, PU_THREADS, 0, c->stream, c->pt_sposA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
+                           c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW, d_flags ? (uint32_t *)nullptr : c->d_wflags);
+        HIPCHK(c, hipGetLastError());
+    }
     if (profile) {
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->pt_timed_keys = n;
@@ -1862,6 +2051,14 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         if (cfg->flags & NKML_F_COUNT_PARTITIONED) want = true;
         if (cfg->flags & NKML_F_COUNT_ATOMIC) want = false;
         c->partitioned = can && want;
+        // the hashed table's partitioned path (k > 16): same conditions on depth, flags and batch size
+        const bool can_hp = cfg->ksize > 16 && cfg->depth <= (int32_t)PT_MAX_DEPTH_WIDE && !(cfg->flags & NKML_F_EXACT_COUNTS) &&
+                            cfg->max_batch_bases < (1ull << 32) - (4ull << 20);
+        bool want_hp = true;
+        if (env && (env[0] == '0' || env[0] == '1')) want_hp = env[0] == '1';
+        if (cfg->flags & NKML_F_COUNT_PARTITIONED) want_hp = true;
+        if (cfg->flags & NKML_F_COUNT_ATOMIC) want_hp = false;
+        if (can_hp && want_hp) c->partitioned = c->hashpart = true;
     }
     c->n_shards = 1; // (the memset above also wiped the member initialisers)
     c->shard = 0;
@@ -1942,6 +2139,7 @@ void nkml_destroy(nkml_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots); hipFree(c->spare_slots);
+    hipFree(c->hp_table); hipFree(c->hp_keysA); hipFree(c->hp_keysB); hipFree(c->hp_done);
     hipFree(c->pt_table); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flagsA);
     hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
     hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB);
@@ -1975,6 +2173,7 @@ int nkml_reset(nkml_ctx *c)
     c->pt_timing_pending = false;
     c->staged_pending = false;
     c->used_bound = 0;
+    c->hp_unique_before = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return NKML_OK;
 }
@@ -2006,7 +2205,7 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     memset(out, 0, sizeof *out);
     out->unique_kmers = c->h_ctr->unique;
     out->capacity = c->capacity;
-    out->table_bytes = c->partitioned ? c->capacity * (c->pt_wide ? 2 : 1) : c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
+    out->table_bytes = c->hashpart ? c->capacity * sizeof(unsigned long long) : c->partitioned ? c->capacity * (c->pt_wide ? 2 : 1) : c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
     out->kmers_counted = c->h_ctr->counted;
     out->kmers_saturated = c->h_ctr->saturated;
     out->crossing_kmers = c->h_ctr->total_cross;
@@ -2035,7 +2234,7 @@ int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
 {
     if (!c || !d_keys || !d_flags || (n_keys & 15)) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->partitioned) return run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, 0, d_flags, false);
+    if (c->partitioned) return run_count_partitioned(c, d_keys, n_keys, 0, d_flags, false);
     return run_count(c, d_keys, n_keys, d_flags);
 }
 
@@ -2046,7 +2245,7 @@ int nkml_seed_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
     if (c->partitioned) {
-        if ((rc = run_count_partitioned(c, (const uint32_t *)d_keys, n_keys, 0, nullptr, true)) != NKML_OK) return rc;
+        if ((rc = run_count_partitioned(c, d_keys, n_keys, 0, nullptr, true)) != NKML_OK) return rc;
         return fetch_counters(c);
     }
     if ((rc = ensure_capacity(c, n_keys, nullptr, nullptr)) != NKML_OK) return rc;
@@ -2103,7 +2302,7 @@ int nkml_set_shard(nkml_ctx *c, uint32_t shard, uint32_t n_shards)
 {
     if (!c) return NKML_E_ARG;
     if (n_shards == 0 || shard >= n_shards || n_shards > 65535) return fail(c, NKML_E_ARG, "shard %u of %u", shard, n_shards);
-    if (n_shards > 1 && !c->partitioned) return fail(c, NKML_E_STATE, "table shards need the partitioned counting path");
+    if (n_shards > 1 && (!c->partitioned || c->hashpart)) return fail(c, NKML_E_STATE, "table shards need the partitioned counting path of the direct table (k <= 15)");
     c->n_shards = n_shards;
     c->shard = shard;
     return NKML_OK;
@@ -2402,7 +2601,9 @@ static int dump_table_into(nkml_ctx *c, unsigned long long *d_codes, uint32_t *d
                            uint32_t *counts, uint64_t max_entries, uint64_t *n_entries)
 {
     HIPCHK(c, hipMemsetAsync(d_n, 0, sizeof(unsigned long long), c->stream));
-    if (c->partitioned) {
+    if (c->hashpart) {
+        hipLaunchKernelGGL(k_hp_dump, GRID_PERSIST, 256, 0, c->stream, c->hp_table, c->hp_log2_bucket, d_codes, d_cnts, max_entries, d_n);
+    } else if (c->partitioned) {
         if (c->pt_wide)
             hipLaunchKernelGGL((k_pt_dump<uint16_t>), GRID_PERSIST, 256, 0, c->stream, (const uint16_t *)c->pt_table, c->capacity, d_codes, d_cnts, max_entries, d_n);
         else

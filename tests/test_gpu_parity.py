@@ -112,6 +112,58 @@ def test_random_reads_small_keyspace(nk, oracle_lib, k, depth, canonical, chunk)
         assert st["kmers_counted"] == int(total.sum())
 
 
+@pytest.mark.parametrize("k,depth,canonical,log2_bucket,per_batch", [
+    (17, 3, False, None, 700), (21, 2, True, None, 512), (25, 4, True, None, 2000), (31, 3, False, None, 300), (31, 50, True, None, 700),
+    (25, 100, True, None, 2000), (21, 200, False, None, 2000),
+    (25, 4, True, 2, 2000),    # four slots per bucket to begin with: the table doubles between batches and inside a batch
+    (31, 3, False, 3, 150), (19, 5, True, 2, 5000),
+])
+@pytest.mark.parametrize("on", [True, False])
+def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, log2_bucket, per_batch, on):
+    """k > 16 through the partitioned path of the hashed table (buckets counted in LDS) and through the atomic path:
+    per-read counters and distinct k-mers against the oracle, table dump against the oracle's counts."""
+    if not on and log2_bucket is not None:
+        pytest.skip("table geometry of the partitioned path only")
+    rng = np.random.default_rng(7000 + k * 7 + depth)
+    reads = random_reads(rng, 600, k, 4 * k + 40, b"AC") + random_reads(rng, 900, k, 200, b"ACGT", 0.01) \
+        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"G" * 64, b"C" * 33, b"N" * 40] * 3 + [b"G" * 150] * 400
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    o = oracle_lib(k, depth, canonical)
+    seeds = [r for r in reads[:100] if len(r) > k]
+    for r in seeds:
+        o.seed(r)
+    want = [o.read(r) for r in reads]
+    old = os.environ.get("NKML_HP_LOG2_BUCKET")
+    if log2_bucket is not None:
+        os.environ["NKML_HP_LOG2_BUCKET"] = str(log2_bucket)
+    try:
+        with partitioned_mode(on), nk.KmerNormaliser(k, depth, 0.9, canonical, max_batch_reads=per_batch, max_batch_bases=per_batch * 200) as g:
+            st = g.stats()
+            assert st["partitioned"] == (1 if on else 0)
+            cap0 = st["capacity"]
+            seq, off = nk.KmerNormaliser._concat(seeds)
+            g.seed_batch(seq, off)
+            ok, high, total = g.process_sequence_single(reads)
+            np.testing.assert_array_equal(high, [w[1] for w in want])
+            np.testing.assert_array_equal(total, [w[2] for w in want])
+            assert g.unique_kmers == o.unique
+            st = g.stats()
+            assert st["kmers_counted"] == int(total.sum())
+            if log2_bucket is not None:
+                assert cap0 == 65536 << log2_bucket and st["resizes"] > 0 and st["capacity"] > cap0
+            codes, counts, n = g.dump_table()
+            assert n == o.unique
+            # the partitioned path's counts stop growing at 32767, the atomic path freezes the counts of saturated k-mers
+            for code, cnt in list(zip(codes.tolist(), counts.tolist()))[:3000]:
+                true = o.count_of(code)
+                assert cnt == true or (cnt >= depth - 1 and true >= cnt), (code, cnt, true)
+    finally:
+        if old is None:
+            os.environ.pop("NKML_HP_LOG2_BUCKET", None)
+        else:
+            os.environ["NKML_HP_LOG2_BUCKET"] = old
+
+
 def test_batch_cut_invariance(nk):
     """The stream may be cut into batches anywhere: one batch, many batches and one read per batch agree."""
     rng = np.random.default_rng(5)
