@@ -1318,7 +1318,11 @@ uint64_t default_hashed_capacity(int memory_gb)
 }
 
 constexpr int HP_MAX_LOG2_BUCKET = 16;                                        // 2^32 slots = 32 GiB of table
-constexpr uint32_t HP_MAX_GRID = 65536u << 6;                                 // most bucket workgroups of one launch
+constexpr uint32_t HP_MAX_GRID = 65536u << HB_MAX_SUBS_LOG2;                  // sub-ranges of all buckets at most
+constexpr int HP_DEFAULT_LOG2_LOCAL = 13;                                     // 8192 slots x 12 bytes of LDS per bucket workgroup (measured best: 13 > 12 > 11)
+
+// sub-range geometry of a table with 2^log2_bucket slots per bucket
+HpGeom hp_geom(const nkml_ctx *c, int log2_bucket);
 
 // bytes of the partitioned path's table: one entry per k-mer, at least one bucket
 uint64_t pt_table_bytes(const nkml_ctx *c)
@@ -1335,7 +1339,7 @@ int alloc_table(nkml_ctx *c)
             c->capacity = default_hashed_capacity(c->cfg.memory_gb);
             c->hp_log2_bucket = 0;
             while ((65536ull << c->hp_log2_bucket) < c->capacity) c->hp_log2_bucket++;
-            c->hp_log2_local_max = HB_MAX_SLOTS_LOG2;
+            c->hp_log2_local_max = HP_DEFAULT_LOG2_LOCAL;
             if (const char *e = getenv("NKML_HP_LOG2_LOCAL")) { // tuning aid
                 const int v = atoi(e);
                 if (v >= 6 && v <= HB_MAX_SLOTS_LOG2) c->hp_log2_local_max = v;
@@ -1819,20 +1823,25 @@ __global__ void __launch_bounds__(256) k_hp_remap_done(const uint32_t *__restric
     tally_new[2 * i + 1] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+HpGeom hp_geom(const nkml_ctx *c, int log2_bucket)
+{
+    int ll = log2_bucket < c->hp_log2_local_max ? log2_bucket : c->hp_log2_local_max;
+    if (log2_bucket - ll > HB_MAX_SUBS_LOG2) ll = log2_bucket - HB_MAX_SUBS_LOG2;
+    return HpGeom{log2_bucket, ll};
+}
+
 int hp_grow(nkml_ctx *c, bool batch_under_way)
 {
-    if (c->hp_log2_bucket + 1 > HP_MAX_LOG2_BUCKET || (c->hp_log2_bucket + 1 > c->hp_log2_local_max && (65536ull << (c->hp_log2_bucket + 1 - c->hp_log2_local_max)) > HP_MAX_GRID))
+    if (c->hp_log2_bucket + 1 > HP_MAX_LOG2_BUCKET || hp_geom(c, c->hp_log2_bucket + 1).log2_local > HB_MAX_SLOTS_LOG2)
         return fail(c, NKML_E_NOMEM, "hashed table cannot grow beyond 2^%d slots", 16 + c->hp_log2_bucket);
-    const int lmax = c->hp_log2_local_max;
-    const HpGeom og = {c->hp_log2_bucket, c->hp_log2_bucket < lmax ? c->hp_log2_bucket : lmax};
-    const HpGeom ng = {c->hp_log2_bucket + 1, c->hp_log2_bucket + 1 < lmax ? c->hp_log2_bucket + 1 : lmax};
+    const HpGeom og = hp_geom(c, c->hp_log2_bucket), ng = hp_geom(c, c->hp_log2_bucket + 1);
     const uint64_t ncap = c->capacity * 2;
     unsigned long long *nt = nullptr;
     HIPCHK(c, hipMalloc(&nt, ncap * sizeof(unsigned long long)));
     hipLaunchKernelGGL(k_hp_grow, 65536u << (ng.log2_bucket - ng.log2_local), HB_THREADS, ((size_t)8) << ng.log2_local, c->stream, c->hp_table, og, nt, ng,
                        c->d_ctr);
     HIPCHK(c, hipGetLastError());
-    if (batch_under_way && ng.log2_bucket > ng.log2_local) { // the number of workgroups per bucket doubles
+    if (batch_under_way && ng.log2_bucket - ng.log2_local > og.log2_bucket - og.log2_local) { // the sub-ranges per bucket double
         const uint32_t n_old = 65536u << (og.log2_bucket - og.log2_local);
         uint32_t *d2 = nullptr;
         uint4 *t2 = nullptr;
@@ -1910,20 +1919,18 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     hipLaunchKernelGGL((k_hp_scatter<false>), gb, PT_THREADS, 0, c->stream, c->hp_keysA, (uint64_t)0, n_a, HP_SHIFT_B, c->pt_scanB, c->hp_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
     {
-        // room for one doubling of the workgroups inside this batch
-        const int ll = c->hp_log2_bucket < c->hp_log2_local_max ? c->hp_log2_bucket : c->hp_log2_local_max;
-        uint64_t marks = (uint64_t)131072 << (c->hp_log2_bucket - ll);
-        if (marks > HP_MAX_GRID) marks = HP_MAX_GRID;
-        HIPCHK(c, hipMemsetAsync(c->hp_done, 0, marks * sizeof(uint32_t), c->stream));
+        const HpGeom g0 = hp_geom(c, c->hp_log2_bucket);
+        HIPCHK(c, hipMemsetAsync(c->hp_done, 0, ((uint64_t)65536 << (g0.log2_bucket - g0.log2_local)) * sizeof(uint32_t), c->stream));
     }
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    uint32_t grid = 0;
+    uint32_t n_ranges = 0;
     for (int attempt = 0;; attempt++) {
-        const HpGeom geo = {c->hp_log2_bucket, c->hp_log2_bucket < c->hp_log2_local_max ? c->hp_log2_bucket : c->hp_log2_local_max};
-        grid = 65536u << (geo.log2_bucket - geo.log2_local);
+        const HpGeom geo = hp_geom(c, c->hp_log2_bucket);
+        n_ranges = 65536u << (geo.log2_bucket - geo.log2_local);
         const size_t lds = ((size_t)12) << geo.log2_local;
-        hipLaunchKernelGGL(k_hp_count_bucket, grid, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_scanB, c->pt_pad, c->hp_table, geo,
-                           (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr);
+        // the first pass's output is free by now: the workgroups regroup their buckets' keys into it
+        hipLaunchKernelGGL(k_hp_count_bucket, 65536u, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_scanB, c->pt_pad, c->hp_table, geo,
+                           (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr, c->hp_keysA);
         HIPCHK(c, hipGetLastError());
         if (profile && attempt == 0) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         if ((rc = fetch_counters(c)) != NKML_OK) return rc; // did every bucket fit?
@@ -1936,7 +1943,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
 #ifdef HB_STAMP
     hipLaunchKernelGGL(k_hb_stamp_print, 1, 1, 0, c->stream);
 #endif
-    hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, grid, c->d_ctr);
+    hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, n_ranges, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
         hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
