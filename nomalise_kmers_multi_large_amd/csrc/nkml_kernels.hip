@@ -1228,6 +1228,7 @@ struct nkml_ctx {
     uint32_t *hp_done;       // per bucket workgroup: its part of the current batch is committed
     int hp_log2_bucket;      // slots per bucket = 2^hp_log2_bucket; capacity = 2^(16 + hp_log2_bucket)
     int hp_log2_local_max;   // slots one bucket workgroup holds in LDS at most (2^this)
+    uint64_t hp_leave_slots; // the table moves to the atomic path once it has more slots than this (0: never)
     uint64_t hp_unique_before; // stored k-mers when the last batch began (what a batch adds is the best guess for the next one)
     uint64_t pt_timed_keys;
     bool pt_timing_pending;
@@ -1396,6 +1397,22 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->slots, c->capacity * sizeof(Slot)));
     }
     HIPCHK(c, hipMalloc(&c->filter, FILTER_WORDS * sizeof(uint32_t)));
+    return NKML_OK;
+}
+
+// lists and sort buffers of the atomic path's order fix-up
+int alloc_atomic_lists(nkml_ctx *c)
+{
+    const uint64_t npos = c->max_words * 16;
+    const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
+    HIPCHK(c, hipMalloc(&c->d_list_sat, per_chunk * c->key_bytes));
+    HIPCHK(c, hipMalloc(&c->d_list_cross, per_chunk * c->key_bytes));
+    HIPCHK(c, hipMalloc(&c->d_occ, npos * sizeof(unsigned long long)));
+    HIPCHK(c, hipMalloc(&c->d_occ_sorted, npos * sizeof(unsigned long long)));
+    size_t tmp = 0;
+    HIPCHK(c, rocprim::radix_sort_keys(nullptr, tmp, c->d_occ, c->d_occ_sorted, (size_t)npos, 0u, 64u, c->stream));
+    c->sort_tmp_bytes = tmp ? tmp : 256;
+    HIPCHK(c, hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes));
     return NKML_OK;
 }
 
@@ -1721,6 +1738,7 @@ int collect_partition_timing(nkml_ctx *c);
 // d_keys == nullptr: the keys of the first pass are recomputed from the context's packed words (n_bases of them
 // prepared); d_flags == nullptr: the result is the context's word flags (one word per 16 positions).
 int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding);
+int collect_partition_timing(nkml_ctx *c);
 
 int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
 {
@@ -1862,6 +1880,78 @@ int hp_grow(nkml_ctx *c, bool batch_under_way)
     c->hp_log2_bucket++;
     c->resizes++;
     return NKML_OK;
+}
+
+// The partitioned path sweeps the whole table through LDS once per batch, the atomic path touches one slot per k-mer
+// occurrence: once the table has grown well beyond a batch's positions, the sweep costs more than the random accesses it
+// replaced (measured on 150-base pairs: 2 M-pair batches break even near 2^30 slots, 0.7 M-pair batches near 2^28).  From
+// then on the context counts on the atomic path: every stored k-mer moves to a table of 16-byte slots (same number of
+// slots; count as it stands; saturated if count >= depth - 1, which is what both paths hold between batches), the
+// partition buffers go, the atomic path's lists come.  Called between batches only.  If the memory for the move is not
+// to be had the context stays where it is.
+__global__ void __launch_bounds__(256) k_hp_to_slots(const unsigned long long *__restrict__ table, int log2_bucket, Slot *__restrict__ slots,
+                                                     uint64_t cap_mask, uint32_t depth, Counters *ctr)
+{
+    const uint64_t cap = (uint64_t)65536 << log2_bucket, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += stride) {
+        const unsigned long long v = table[i];
+        if (!v) continue;
+        const unsigned long long hash = ((i >> log2_bucket) << 48) | (v & HP_KEYMASK), code = unmix64(hash);
+        const uint32_t cnt = (uint32_t)(v >> HP_COUNT_SHIFT) & HP_CMAX;
+        uint64_t h = hash & cap_mask, probes = 0; // find_or_insert starts from mix64(code) = hash
+        for (; probes <= cap_mask; probes++) {
+            if (atomicCAS(&slots[h].key, 0ull, code) == 0ull) {
+                slots[h].count = cnt;
+                slots[h].state = cnt + 1 >= depth ? ST_SAT : 0u;
+                break;
+            }
+            h = (h + 1) & cap_mask;
+        }
+        if (probes > cap_mask) atomicAdd(&ctr->probe_overflow, 1u);
+    }
+}
+
+int hp_leave(nkml_ctx *c)
+{
+    int rc;
+    if ((rc = fetch_counters(c)) != NKML_OK) return rc; // waits for the stream
+    if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
+    c->hp_leave_slots = 0;
+    Slot *ns = nullptr;
+    uint32_t *filter = nullptr;
+    if (hipMalloc(&ns, c->capacity * sizeof(Slot)) != hipSuccess || hipMalloc(&filter, FILTER_WORDS * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(ns);
+        return NKML_OK;
+    }
+    // the partition buffers first: the lists need room too
+    void *gone[] = {c->hp_keysA, c->hp_keysB, c->hp_done, c->pt_flagsA, c->pt_flagsB, c->pt_sposA, c->pt_sposB, c->pt_histA, c->pt_scanA,
+                    c->pt_histB, c->pt_scanB, c->pt_pad, c->pt_startB, c->pt_tally, c->pt_totals, c->pt_chunks};
+    for (void *p : gone) hipFree(p);
+    c->hp_keysA = c->hp_keysB = nullptr;
+    c->hp_done = nullptr;
+    c->pt_flagsA = c->pt_flagsB = nullptr;
+    c->pt_sposA = c->pt_sposB = c->pt_histA = c->pt_scanA = c->pt_histB = c->pt_scanB = c->pt_pad = c->pt_startB = c->pt_totals = c->pt_chunks = nullptr;
+    c->pt_tally = nullptr;
+    c->slots = ns;
+    c->filter = filter;
+    HIPCHK(c, zero_device(ns, c->capacity * sizeof(Slot), c->stream));
+    HIPCHK(c, hipMemsetAsync(filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_hp_to_slots, GRID_PERSIST, 256, 0, c->stream, c->hp_table, c->hp_log2_bucket, ns, c->capacity - 1, (uint32_t)c->cfg.depth, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(c->hp_table));
+    c->hp_table = nullptr;
+    c->partitioned = c->hashpart = false;
+    c->used_bound = c->h_ctr->unique;
+    return alloc_atomic_lists(c);
+}
+
+// before a batch: is it time to leave the partitioned path?
+inline int hp_maybe_leave(nkml_ctx *c)
+{
+    if (!c->hashpart || !c->hp_leave_slots || c->capacity <= c->hp_leave_slots) return NKML_OK;
+    return hp_leave(c);
 }
 
 // The hashed table's partitioned counting of one batch: histogram + two partition passes on the hashes' top 16 bits,
@@ -2078,6 +2168,14 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     const uint64_t npos = c->max_words * 16;
     c->posbits = 0;
     while ((1ull << c->posbits) < npos) c->posbits++;
+    if (c->hashpart) {
+        // chosen by default: stay while the table has at most 1.5 slots per position of a full batch (hp_leave);
+        // asked for by flag or environment: stay for good
+        const char *env = getenv("NKML_PARTITIONED");
+        const bool forced = (cfg->flags & NKML_F_COUNT_PARTITIONED) || (env && env[0] == '1');
+        c->hp_leave_slots = forced ? 0 : npos + npos / 2;
+        if (const char *e = getenv("NKML_HP_LEAVE_SLOTS")) c->hp_leave_slots = strtoull(e, nullptr, 10); // test aid
+    }
 
 #define CREATE_CHK(call)                                                   \
     do {                                                                   \
@@ -2117,17 +2215,7 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     CREATE_HIP(hipMalloc(&c->d_wflags, (c->max_words + 4) * sizeof(uint32_t)));
     CREATE_HIP(hipMalloc(&c->d_high, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
     CREATE_HIP(hipMalloc(&c->d_total, (uint64_t)cfg->max_batch_reads * sizeof(int32_t)));
-    if (!c->partitioned) { // lists and sort buffers of the atomic path's order fix-up
-        const uint64_t per_chunk = npos < c->chunk ? npos : c->chunk;
-        CREATE_HIP(hipMalloc(&c->d_list_sat, per_chunk * c->key_bytes));
-        CREATE_HIP(hipMalloc(&c->d_list_cross, per_chunk * c->key_bytes));
-        CREATE_HIP(hipMalloc(&c->d_occ, npos * sizeof(unsigned long long)));
-        CREATE_HIP(hipMalloc(&c->d_occ_sorted, npos * sizeof(unsigned long long)));
-        size_t tmp = 0;
-        CREATE_HIP(rocprim::radix_sort_keys(nullptr, tmp, c->d_occ, c->d_occ_sorted, (size_t)npos, 0u, 64u, c->stream));
-        c->sort_tmp_bytes = tmp ? tmp : 256;
-        CREATE_HIP(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes));
-    }
+    if (!c->partitioned) CREATE_CHK(alloc_atomic_lists(c));
     CREATE_HIP(hipHostMalloc(&c->h_seq, npos + 64, hipHostMallocDefault));
     CREATE_HIP(hipHostMalloc(&c->h_offsets, ((uint64_t)cfg->max_batch_reads + 1) * sizeof(uint64_t), hipHostMallocDefault));
     CREATE_HIP(hipHostMalloc(&c->h_high, (uint64_t)cfg->max_batch_reads * sizeof(int32_t), hipHostMallocDefault));
@@ -2241,6 +2329,7 @@ int nkml_count_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uin
 {
     if (!c || !d_keys || !d_flags || (n_keys & 15)) return NKML_E_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (int rc = hp_maybe_leave(c)) return rc;
     if (c->partitioned) return run_count_partitioned(c, d_keys, n_keys, 0, d_flags, false);
     return run_count(c, d_keys, n_keys, d_flags);
 }
@@ -2251,6 +2340,7 @@ int nkml_seed_keys_device(nkml_ctx *c, const void *d_keys, uint64_t n_keys)
     if (n_keys == 0) return NKML_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
+    if ((rc = hp_maybe_leave(c)) != NKML_OK) return rc;
     if (c->partitioned) {
         if ((rc = run_count_partitioned(c, d_keys, n_keys, 0, nullptr, true)) != NKML_OK) return rc;
         return fetch_counters(c);
@@ -2283,6 +2373,7 @@ static int process_device(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_o
     if (rc != NKML_OK) return rc;
     if (n_reads == 0) return NKML_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if ((rc = hp_maybe_leave(c)) != NKML_OK) return rc;
     if (c->partitioned) {
         const uint64_t n_keys = (n_bases + 15) / 16 * 16;
         if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
@@ -2346,6 +2437,7 @@ int nkml_process_packed_device(nkml_ctx *c, const uint32_t *d_words, const uint6
     HIPCHK(c, hipMemcpyAsync(c->d_packed, d_words, n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_mark_starts, blocks_for((uint64_t)n_reads + 1), 256, 0, c->stream, d_offsets, n_reads, c->d_startbits);
     HIPCHK(c, hipGetLastError());
+    if ((rc = hp_maybe_leave(c)) != NKML_OK) return rc;
     if (c->partitioned) {
         if ((rc = run_count_partitioned(c, nullptr, n_words * 16, n_bases, nullptr, false)) != NKML_OK) return rc;
         if ((rc = run_reduce_words(c, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
@@ -2440,6 +2532,7 @@ int nkml_seed(nkml_ctx *c, const uint8_t *seq, const uint64_t *offsets, uint32_t
     uint64_t n_bases = 0;
     int rc = stage_host_batch(c, seq, offsets, n_reads, &n_bases);
     if (rc != NKML_OK) return rc;
+    if ((rc = hp_maybe_leave(c)) != NKML_OK) return rc;
     if (c->partitioned) {
         if ((rc = run_prepare(c, c->d_seq, c->d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
         if ((rc = run_count_partitioned(c, nullptr, (n_bases + 15) / 16 * 16, n_bases, nullptr, true)) != NKML_OK) return rc;

@@ -164,6 +164,44 @@ def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, l
             os.environ["NKML_HP_LOG2_BUCKET"] = old
 
 
+def test_hashed_table_moves_from_the_partitioned_to_the_atomic_path(nk, oracle_lib):
+    """The hashed table starts on the partitioned path and, once it has outgrown the batches (here: after its first
+    doubling, by NKML_HP_LEAVE_SLOTS), carries on on the atomic path with every k-mer and count it had: counters of every
+    read, distinct k-mers and the dumped counts against the oracle, across the move."""
+    k, depth = 25, 3
+    rng = np.random.default_rng(4242)
+    reads = random_reads(rng, 2600, 60, 200, b"ACGT", 0.01) + random_reads(rng, 400, k, 90, b"AC") + [b"G" * 150] * 50
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    reads = reads + reads[:700]          # seen again after the move: counts and saturation must have come along
+    o = oracle_lib(k, depth, True)
+    want = [o.read(r) for r in reads]
+    saved = {v: os.environ.get(v) for v in ("NKML_HP_LOG2_BUCKET", "NKML_HP_LEAVE_SLOTS", "NKML_PARTITIONED")}
+    os.environ["NKML_HP_LOG2_BUCKET"] = "2"
+    os.environ["NKML_HP_LEAVE_SLOTS"] = str(65536 << 2)
+    os.environ.pop("NKML_PARTITIONED", None)
+    try:
+        with nk.KmerNormaliser(k, depth, 0.9, True, max_batch_reads=400, max_batch_bases=400 * 200) as g:
+            assert g.stats()["partitioned"] == 1 and g.stats()["capacity"] == 65536 << 2
+            ok, high, total = g.process_sequence_single(reads)
+            st = g.stats()
+            assert st["partitioned"] == 0 and st["capacity"] > 65536 << 2
+            np.testing.assert_array_equal(high, [w[1] for w in want])
+            np.testing.assert_array_equal(total, [w[2] for w in want])
+            assert g.unique_kmers == o.unique
+            assert st["kmers_counted"] == int(total.sum())
+            codes, counts, n = g.dump_table()
+            assert n == o.unique
+            for code, cnt in list(zip(codes.tolist(), counts.tolist()))[:3000]:
+                true = o.count_of(code)
+                assert cnt == true or (cnt >= depth - 1 and true >= cnt), (code, cnt, true)
+    finally:
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
+
+
 def test_batch_cut_invariance(nk):
     """The stream may be cut into batches anywhere: one batch, many batches and one read per batch agree."""
     rng = np.random.default_rng(5)
