@@ -371,7 +371,7 @@ def main():
         # `traffic` is the HBM bytes of the same unit from the rocprofv3 PMC passes recorded in profiles/ (FETCH_SIZE
         # doubled as gfx950 needs for wide streaming reads, plus WRITE_SIZE), when a record for this configuration exists.
         if partitioned and st.get("count_stage_ms"):
-            kernel = "counting stage (k_pt_hist_words .. k_pt_ungather)"
+            kernel = "counting stage (%s_hist_words .. k_pt_ungather)" % ("k_hp" if k > 16 else "k_pt")
             unit_ms = st["count_stage_ms"] / launches
         else:
             kernel = "k_count_words_direct" if k <= 16 else "k_count_words_hashed"
@@ -399,8 +399,11 @@ def main():
                "traffic_over_algorithmic": (traffic / alg_bytes_per_launch) if traffic and alg_bytes_per_launch else None}
         if partitioned:
             bucket_ms = st["count_kernel_ms"] / launches
-            bucket_bytes = 2.0 * st["capacity"] + 2.125 * occ_per_launch  # table sweep (read + write) + 2-byte key in, flag bit out
-            aux["bucket_kernel"] = {"kernel": "k_pt_count_bucket", "avg_launch_ms": bucket_ms, "design_bytes_per_launch": bucket_bytes,
+            if k > 16:  # hashed table: 8-byte slots swept through LDS, 8-byte hash in, flag byte out
+                bucket_bytes, bucket_name = 2.0 * st["table_bytes"] + 9.0 * occ_per_launch, "k_hp_count_bucket"
+            else:       # table sweep (read + write) + 2-byte key in, flag byte out
+                bucket_bytes, bucket_name = 2.0 * st["table_bytes"] + 3.0 * occ_per_launch, "k_pt_count_bucket"
+            aux["bucket_kernel"] = {"kernel": bucket_name, "avg_launch_ms": bucket_ms, "design_bytes_per_launch": bucket_bytes,
                                     "design_GBps": bucket_bytes / (bucket_ms * 1e-3) / 1e9 if bucket_ms > 0 else None}
         result = {
             "metric": "read-pairs/sec at k=%d, 150 bp PE (+ unique-kmers/sec)" % k,
@@ -419,7 +422,7 @@ def main():
                 n_pairs, k, " --canonical" if canonical else "", depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
                     world, "packed reads all-gathered, every GPU counts its shard" if multi_mode == "replicated" else "RCCL all-to-all of k-mers")),
                 "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d (%s)" % (world, multi_mode),
-                "distinct_steps_of_data": data_steps},
+                "distinct_steps_of_data": data_steps, "ksize": k, "canonical": bool(canonical), "partitioned": bool(partitioned)},
             "unique_kmers": unique,
             "unique_kmers_per_s": unique / elapsed,
             "kmer_occurrences_per_s": occ * world / elapsed,
@@ -427,7 +430,8 @@ def main():
             "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_launch": alg_bytes_per_launch}, **aux),
-            "table": {"saturated_fraction": st["kmers_saturated"] / max(1, occ), "crossing_kmers": st["crossing_kmers"],
+            "table": {"table_bytes": st["table_bytes"], "slots": st["capacity"], "resizes": st["resizes"],
+                      "saturated_fraction": st["kmers_saturated"] / max(1, occ), "crossing_kmers": st["crossing_kmers"],
                       "crossing_occurrences": st["crossing_occurrences"]},
         }
         if world == 1 and not args.no_cpu_baseline:
