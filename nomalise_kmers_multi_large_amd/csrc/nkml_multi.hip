@@ -99,6 +99,7 @@ struct nkml_multi {
     uint32_t cap_reads = 0;
     int key_bytes = 4;
     bool use_rccl = false;
+    uint64_t rccl_piece = 512ull << 20; // most bytes of one send / receive (NKML_RCCL_PIECE_BYTES: test aid)
     Rccl rccl;
     std::vector<ncclComm_t> comms;
     // pinned staging of the whole batch
@@ -213,13 +214,19 @@ int exchange(nkml_multi *m, bool forward, size_t elem)
     if (m->use_rccl) {
         // the sending side's data must be complete before its stream sends: keys are (stage_route waited), flags are
         // ordered by the stream itself (the counting kernels run on the same stream)
+        // A segment travels in pieces of at most rccl_piece bytes, the same cuts on both sides: on this stack (RCCL 2.26.6)
+        // a grouped send/receive of more than 1 GiB delivers its first half only (seen through torch's all_to_all_single
+        // with a world of one: 1024 MiB whole, 1025 MiB and up cut at exactly half their bytes, the rest zero; all-gather,
+        // all-reduce and broadcast of the same sizes arrive whole).
         ncclResult_t r = m->rccl.GroupStart();
         for (uint32_t i = 0; i < n && r == ncclSuccess; i++) {
             uint64_t so = 0, ro = 0;
             for (uint32_t j = 0; j < n && r == ncclSuccess; j++) {
-                const uint64_t ns = seg(i, j), nr = seg(j, i);
-                if (ns) r = m->rccl.Send(src_buf(i) + so * elem, ns * elem, ncclUint8, (int)j, m->comms[i], m->sh[i].stream);
-                if (nr && r == ncclSuccess) r = m->rccl.Recv(dst_buf(i) + ro * elem, nr * elem, ncclUint8, (int)j, m->comms[i], m->sh[i].stream);
+                const uint64_t ns = seg(i, j) * elem, nr = seg(j, i) * elem;
+                for (uint64_t at = 0; at < ns && r == ncclSuccess; at += m->rccl_piece)
+                    r = m->rccl.Send(src_buf(i) + so + at, ns - at < m->rccl_piece ? ns - at : m->rccl_piece, ncclUint8, (int)j, m->comms[i], m->sh[i].stream);
+                for (uint64_t at = 0; at < nr && r == ncclSuccess; at += m->rccl_piece)
+                    r = m->rccl.Recv(dst_buf(i) + ro + at, nr - at < m->rccl_piece ? nr - at : m->rccl_piece, ncclUint8, (int)j, m->comms[i], m->sh[i].stream);
                 so += ns;
                 ro += nr;
             }
@@ -399,6 +406,10 @@ int nkml_multi_create(const nkml_config *cfg, const int32_t *devices, uint32_t n
             if (devices[i] == devices[j]) distinct = false;
     const char *tr = getenv("NKML_TRANSPORT");
     m->use_rccl = tr ? strcmp(tr, "rccl") == 0 : (distinct && n_devices > 1);
+    if (const char *e = getenv("NKML_RCCL_PIECE_BYTES")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 16 && v <= (1ull << 30)) m->rccl_piece = v & ~15ull;
+    }
     if (m->use_rccl && !distinct) return mfail(m, NKML_E_ARG, "RCCL needs a GPU of its own for every shard (NKML_TRANSPORT=copy for shards that share one)");
     for (uint32_t i = 0; i < n_devices; i++) {
         Shard &s = m->sh[i];

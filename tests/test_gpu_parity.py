@@ -936,6 +936,38 @@ def test_multi_device_table_equals_single_stream(nk, oracle_lib, devices, transp
             os.environ["NKML_TRANSPORT"] = old
 
 
+@pytest.mark.parametrize("piece,pairs", [(1 << 16, 20000), (0, 500000)])
+def test_rccl_transport_moves_large_segments_in_pieces(nk, piece, pairs):
+    """The C host's RCCL send/receive transport (a world of one: all a one-GPU box can run) against the single table:
+    with pieces of 64 KiB every segment takes many sends, and with the default piece a batch of 0.5 M pairs at k=25
+    sends 1.2 GB of k-mers to the one shard - more than the 1 GiB beyond which this stack delivers half a message."""
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.normaliser import MultiDeviceNormaliser
+    blocks = list(synth.pair_blocks(pairs, seed=3, transcripts=max(50, pairs // 1000)))
+    seq, off = synth.interleave(np.concatenate([b[0] for b in blocks]), np.concatenate([b[1] for b in blocks]))
+    off = off.astype(np.uint64)
+    nr, nb = len(off) - 1, len(seq)
+    saved = {v: os.environ.get(v) for v in ("NKML_TRANSPORT", "NKML_RCCL_PIECE_BYTES")}
+    os.environ["NKML_TRANSPORT"] = "rccl"
+    if piece:
+        os.environ["NKML_RCCL_PIECE_BYTES"] = str(piece)
+    try:
+        with MultiDeviceNormaliser([0], 25, 100, 0.9, True, max_batch_reads=nr, max_batch_bases=nb) as g, \
+                nk.KmerNormaliser(25, 100, 0.9, True, max_batch_reads=nr, max_batch_bases=nb) as one:
+            for _ in range(2):   # the second batch finds the k-mers of the first
+                h, t = g.process_batch(seq, off)
+                h1, t1 = one.process_batch(seq, off)
+                np.testing.assert_array_equal(h, h1)
+                np.testing.assert_array_equal(t, t1)
+            assert g.unique_kmers == one.unique_kmers and int(h.sum()) > 0
+    finally:
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
+
+
 def o_unique_after_seeding(oracle_lib, k, depth, canonical, seeds):
     o = oracle_lib(k, depth, canonical)
     for r in seeds:
