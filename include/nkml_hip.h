@@ -68,12 +68,18 @@ typedef struct nkml_config {
                                   ref:354-385); costs one more atomic per saturated occurrence and, for k <= 16,
                                   a second 4^k-entry counter array */
 #define NKML_F_COUNT_ATOMIC 4u /* count with atomics on the table even where the partitioned path would be chosen */
-#define NKML_F_COUNT_PARTITIONED 8u /* count by radix-partitioning each batch's k-mers into 2^14-code buckets that are
-                                  counted in LDS against a table of one byte per k-mer (two for depth > 127), wherever
-                                  that path can run (k <= 15, depth <= 16383, no NKML_F_EXACT_COUNTS).  With neither flag the library
-                                  chooses: partitioned at k = 15 and, for batches up to about 2 M pairs of 150 bases,
-                                  at k = 14; atomics otherwise; the environment variable NKML_PARTITIONED=0/1
-                                  overrides that choice.  Results are identical either way. */
+#define NKML_F_COUNT_PARTITIONED 8u /* count by radix-partitioning each batch's k-mers into buckets that are counted in LDS,
+                                  wherever that path can run (depth <= 16383, no NKML_F_EXACT_COUNTS).  k <= 15: buckets of
+                                  2^14 codes against a table of one byte per k-mer (two for depth > 127).  k > 16: buckets by
+                                  the top 16 bits of a hash of the code against a table of 8-byte slots that is swept once
+                                  per batch and doubles when a bucket fills up.  With neither flag the library chooses:
+                                  partitioned at k = 15 and, for batches up to about 2 M pairs of 150 bases, at k = 14;
+                                  partitioned at k > 16 while the table has at most 1.5 slots per position of a full batch,
+                                  atomics from then on (the stored k-mers move over, between two batches, for good: the
+                                  sweep of a large table costs more than the random accesses it replaces - nkml_stats
+                                  .partitioned tells which path a context is on); atomics otherwise.  The environment
+                                  variable NKML_PARTITIONED=0/1 overrides the choice like the flags.  Per-read results are
+                                  identical either way; dumped counts of k-mers past the depth differ (see nkml_dump_table). */
 
 typedef struct nkml_stats {
     uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */
@@ -246,7 +252,8 @@ int nkml_multi_dump_table(nkml_multi *m, uint64_t *codes, uint32_t *counts, uint
 /* Table dump for --print (print_kmer_table, ref:354-385): up to max_entries (code, count) pairs of every
  * stored k-mer, unsorted like the reference; *n_entries gets the number available. Host arrays, synchronous.
  * Without NKML_F_EXACT_COUNTS a k-mer's count stops growing once it has reached depth-1 at the start of a
- * counting pass (from then on every occurrence is high whatever the count). */
+ * counting pass (from then on every occurrence is high whatever the count); on the partitioned paths it keeps
+ * growing up to 127 (one-byte entries), 32767 (two-byte entries, hashed slots) and stops there. */
 int nkml_dump_table(nkml_ctx *ctx, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries);
 
 #ifdef __cplusplus
