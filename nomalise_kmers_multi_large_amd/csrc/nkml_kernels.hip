@@ -1343,7 +1343,7 @@ int alloc_table(nkml_ctx *c)
             c->hp_log2_local_max = HP_DEFAULT_LOG2_LOCAL;
             if (const char *e = getenv("NKML_HP_LOG2_LOCAL")) { // tuning aid
                 const int v = atoi(e);
-                if (v >= 6 && v <= HB_MAX_SLOTS_LOG2) c->hp_log2_local_max = v;
+                if (v >= 2 && v <= HB_MAX_SLOTS_LOG2) c->hp_log2_local_max = v; // at least one set of slots
             }
             if (const char *e = getenv("NKML_HP_LOG2_BUCKET")) { // test aid: a tiny table, so that small inputs make it grow
                 const int v = atoi(e);

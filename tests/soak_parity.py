@@ -2,6 +2,7 @@
 canonical, read mix (random, low-complexity, tandem repeats, N runs, poly-G floods), random batch cuts - through the
 C ABI on the partitioned and the atomic counting path, each compared read by read with the CPU oracle.
 python tests/soak_parity.py [cases] [seed]   (not collected by pytest: a long run for the GPU box)"""
+import os
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -45,17 +46,25 @@ def make_read(k, pool):
 bad = 0
 for case in range(cases):
     k = int(rng.choice([5, 7, 9, 11, 13, 14, 15, 16, 17, 21, 25, 31]))
-    depth = int(rng.choice([2, 3, 5, 20, 100, 127, 300]))
+    depth = int(rng.choice([2, 3, 5, 20, 100, 127, 300, 1000]))
     canonical = bool(rng.integers(0, 2))
     pool = ACGT[rng.integers(0, 4, int(rng.choice([400, 3000, 40000])))]
     reads = [make_read(k, pool) for _ in range(int(rng.integers(1, 700)))]
     o = Oracle(k, depth, canonical)
     want = [o.read(r) for r in reads]
     want_h, want_t = np.array([w[1] for w in want]), np.array([w[2] for w in want])
-    modes = [0]
-    if k <= 15 and depth <= 127:
-        modes = [binding.NKML_F_COUNT_ATOMIC, binding.NKML_F_COUNT_PARTITIONED]
+    modes = [binding.NKML_F_COUNT_ATOMIC, binding.NKML_F_COUNT_PARTITIONED] if k != 16 else [0]
     for flags in modes:
+        # geometry of the hashed table's partitioned path: tiny buckets and LDS tables make it grow, cut buckets into
+        # sub-ranges and (with a low limit) move to the atomic path in the middle of the stream
+        for var in ("NKML_HP_LOG2_BUCKET", "NKML_HP_LOG2_LOCAL", "NKML_HP_LEAVE_SLOTS"):
+            os.environ.pop(var, None)
+        if k > 16 and flags == binding.NKML_F_COUNT_PARTITIONED:
+            os.environ["NKML_HP_LOG2_BUCKET"] = str(int(rng.choice([2, 3, 4, 6])))
+            if rng.random() < 0.7:
+                os.environ["NKML_HP_LOG2_LOCAL"] = str(int(rng.choice([2, 3, 4, 5])))
+            if rng.random() < 0.3:
+                os.environ["NKML_HP_LEAVE_SLOTS"] = str(65536 << int(rng.choice([3, 4, 5])))
         g = KmerNormaliser(k, depth, 0.9, canonical, max_batch_reads=1024, max_batch_bases=1 << 19, flags=flags,
                            chunk_bases=int(rng.choice([0, 64, 4096])))
         at, hs, ts = 0, [], []

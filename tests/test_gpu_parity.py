@@ -117,6 +117,9 @@ def test_random_reads_small_keyspace(nk, oracle_lib, k, depth, canonical, chunk)
     (25, 100, True, None, 2000), (21, 200, False, None, 2000),
     (25, 4, True, 2, 2000),    # four slots per bucket to begin with: the table doubles between batches and inside a batch
     (31, 3, False, 3, 150), (19, 5, True, 2, 5000),
+    # a workgroup's LDS table of 4 (8, 16) slots: buckets of several sub-ranges, their keys regrouped by sub-range first
+    # (2-8 sub-ranges: ballots; more: LDS counters), one bucket with more keys than the regrouping's 16-bit index holds
+    (25, 4, True, (2, 2), 2000), (31, 3, False, (2, 3), 5000), (21, 100, True, (3, 2), 5000), (23, 2, False, (2, 4), 300),
 ])
 @pytest.mark.parametrize("on", [True, False])
 def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, log2_bucket, per_batch, on):
@@ -124,9 +127,13 @@ def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, l
     per-read counters and distinct k-mers against the oracle, table dump against the oracle's counts."""
     if not on and log2_bucket is not None:
         pytest.skip("table geometry of the partitioned path only")
+    log2_local = None
+    if isinstance(log2_bucket, tuple):
+        log2_bucket, log2_local = log2_bucket
     rng = np.random.default_rng(7000 + k * 7 + depth)
     reads = random_reads(rng, 600, k, 4 * k + 40, b"AC") + random_reads(rng, 900, k, 200, b"ACGT", 0.01) \
-        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"G" * 64, b"C" * 33, b"N" * 40] * 3 + [b"G" * 150] * 400
+        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"G" * 64, b"C" * 33, b"N" * 40] * 3 \
+        + [b"G" * 150] * (700 if log2_local else 400)
     reads = [reads[i] for i in rng.permutation(len(reads))]
     o = oracle_lib(k, depth, canonical)
     seeds = [r for r in reads[:100] if len(r) > k]
@@ -134,8 +141,11 @@ def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, l
         o.seed(r)
     want = [o.read(r) for r in reads]
     old = os.environ.get("NKML_HP_LOG2_BUCKET")
+    old_local = os.environ.get("NKML_HP_LOG2_LOCAL")
     if log2_bucket is not None:
         os.environ["NKML_HP_LOG2_BUCKET"] = str(log2_bucket)
+    if log2_local is not None:
+        os.environ["NKML_HP_LOG2_LOCAL"] = str(log2_local)
     try:
         with partitioned_mode(on), nk.KmerNormaliser(k, depth, 0.9, canonical, max_batch_reads=per_batch, max_batch_bases=per_batch * 200) as g:
             st = g.stats()
@@ -158,10 +168,11 @@ def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, l
                 true = o.count_of(code)
                 assert cnt == true or (cnt >= depth - 1 and true >= cnt), (code, cnt, true)
     finally:
-        if old is None:
-            os.environ.pop("NKML_HP_LOG2_BUCKET", None)
-        else:
-            os.environ["NKML_HP_LOG2_BUCKET"] = old
+        for var, val in (("NKML_HP_LOG2_BUCKET", old), ("NKML_HP_LOG2_LOCAL", old_local)):
+            if val is None:
+                os.environ.pop(var, None)
+            else:
+                os.environ[var] = val
 
 
 def test_hashed_table_moves_from_the_partitioned_to_the_atomic_path(nk, oracle_lib):
