@@ -1246,6 +1246,12 @@ struct nkml_ctx {
     uint64_t *d_offsets;
     uint32_t *d_packed, *d_startbits;
     uint32_t n_shards = 1, shard = 0; // replicated-reads mode: this context counts only the k-mers of its shard
+    // ... which it first pulls together into a key array (set up by nkml_set_shard; nullptr: the passes blank the others' k-mers)
+    uint32_t *sh_keys, *sh_tile_count, *sh_tile_base;
+    uint16_t *sh_own;       // per packed word: which of its 16 windows hold a k-mer of this shard
+    uint8_t *sh_flags;
+    void *sh_scan_tmp;
+    size_t sh_scan_tmp_bytes;
     uint32_t *d_wflags;     // per packed word: HIGH bits (low half) and LOW bits (high half) of its 16 windows
     int32_t *d_high, *d_total;
 
@@ -1734,6 +1740,7 @@ int run_reduce(nkml_ctx *c, const uint8_t *d_flags, const uint64_t *d_offsets, u
 // Partitioned counting of a key array (k <= 15): two stable radix passes, one workgroup per bucket, two reverse
 // passes for the flags.  Nothing here waits for the device.
 int collect_partition_timing(nkml_ctx *c);
+int run_count_shard(nkml_ctx *c, uint64_t n_words, uint64_t n_bases);
 
 // d_keys == nullptr: the keys of the first pass are recomputed from the context's packed words (n_bases of them
 // prepared); d_flags == nullptr: the result is the context's word flags (one word per 16 positions).
@@ -2050,6 +2057,39 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     return NKML_OK;
 }
 
+// Replicated-reads mode: this shard's k-mers of the batch are pulled together (stream order kept) and counted as a key
+// array; the flags go back to the packed words' flag words.  Waits once for the number of k-mers the shard owns.
+int run_count_shard(nkml_ctx *c, uint64_t n_words, uint64_t n_bases)
+{
+    const uint32_t tiles = (uint32_t)((n_words + 255) / 256);
+    const int k = c->cfg.ksize;
+#define SH_LAUNCH(KERNEL, ...)                                                                                                               \
+    do {                                                                                                                                     \
+        if (c->cfg.canonical)                                                                                                                \
+            hipLaunchKernelGGL((KERNEL<true>), tiles, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, __VA_ARGS__);      \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((KERNEL<false>), tiles, 256, 0, c->stream, c->d_packed, c->d_startbits, n_bases, n_words, k, __VA_ARGS__);     \
+    } while (0)
+    HIPCHK(c, hipMemsetAsync(c->sh_tile_count + tiles, 0, sizeof(uint32_t), c->stream));
+    SH_LAUNCH(k_sh_count, c->n_shards, c->shard, c->sh_own, c->sh_tile_count);
+    HIPCHK(c, hipGetLastError());
+    size_t tmp = c->sh_scan_tmp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->sh_scan_tmp, tmp, c->sh_tile_count, c->sh_tile_base, 0u, (size_t)tiles + 1, rocprim::plus<uint32_t>(), c->stream));
+    uint32_t *h_own = c->h_route_starts + 70;
+    HIPCHK(c, hipMemcpyAsync(h_own, c->sh_tile_base + tiles, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t n_own = *h_own, n16 = (n_own + 15) & ~15ull;
+    if (n16 > n_own) HIPCHK(c, hipMemsetAsync(c->sh_keys + n_own, 0, (n16 - n_own) * sizeof(uint32_t), c->stream));
+    SH_LAUNCH(k_sh_compact, c->sh_own, c->sh_tile_base, c->sh_keys);
+    HIPCHK(c, hipGetLastError());
+    int rc = NKML_OK;
+    if (n16 && (rc = run_count_partitioned(c, c->sh_keys, n16, 0, c->sh_flags, false)) != NKML_OK) return rc;
+    hipLaunchKernelGGL(k_sh_expand, tiles, 256, 0, c->stream, c->sh_own, n_words, c->sh_tile_base, c->sh_flags, c->d_wflags);
+    HIPCHK(c, hipGetLastError());
+#undef SH_LAUNCH
+    return NKML_OK;
+}
+
 // read back the event pairs of the last partitioned batch (after the stream has been waited for)
 int collect_partition_timing(nkml_ctx *c)
 {
@@ -2242,6 +2282,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
     hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
+    hipFree(c->sh_keys); hipFree(c->sh_own); hipFree(c->sh_flags); hipFree(c->sh_tile_count); hipFree(c->sh_tile_base); hipFree(c->sh_scan_tmp);
     hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
     if (c->h_route_starts) hipHostFree(c->h_route_starts);
@@ -2403,6 +2444,22 @@ int nkml_set_shard(nkml_ctx *c, uint32_t shard, uint32_t n_shards)
     if (n_shards > 1 && (!c->partitioned || c->hashpart)) return fail(c, NKML_E_STATE, "table shards need the partitioned counting path of the direct table (k <= 15)");
     c->n_shards = n_shards;
     c->shard = shard;
+    const char *env = getenv("NKML_SHARD_COMPACT");
+    if (n_shards > 1 && !c->sh_keys && !(env && env[0] == '0')) {
+        // the shard's k-mers are pulled together before counting (run_count_shard): key and flag array for the worst case
+        // (every k-mer of the batch in this shard), one count per tile of 256 packed words
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        const uint64_t npos = c->max_words * 16, tiles = (c->max_words + 255) / 256 + 1;
+        HIPCHK(c, hipMalloc(&c->sh_keys, (npos + 16) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->sh_flags, npos + 16));
+        HIPCHK(c, hipMalloc(&c->sh_own, (c->max_words + 256) * sizeof(uint16_t)));
+        HIPCHK(c, hipMalloc(&c->sh_tile_count, tiles * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->sh_tile_base, tiles * sizeof(uint32_t)));
+        size_t tmp = 0;
+        HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, c->sh_tile_count, c->sh_tile_base, 0u, (size_t)tiles, rocprim::plus<uint32_t>(), c->stream));
+        c->sh_scan_tmp_bytes = tmp ? tmp : 256;
+        HIPCHK(c, hipMalloc(&c->sh_scan_tmp, c->sh_scan_tmp_bytes));
+    }
     return NKML_OK;
 }
 
@@ -2439,7 +2496,9 @@ int nkml_process_packed_device(nkml_ctx *c, const uint32_t *d_words, const uint6
     HIPCHK(c, hipGetLastError());
     if ((rc = hp_maybe_leave(c)) != NKML_OK) return rc;
     if (c->partitioned) {
-        if ((rc = run_count_partitioned(c, nullptr, n_words * 16, n_bases, nullptr, false)) != NKML_OK) return rc;
+        if (c->n_shards > 1 && c->sh_keys) rc = run_count_shard(c, n_words, n_bases);
+        else rc = run_count_partitioned(c, nullptr, n_words * 16, n_bases, nullptr, false);
+        if (rc != NKML_OK) return rc;
         if ((rc = run_reduce_words(c, d_offsets, n_reads, d_high, d_total)) != NKML_OK) return rc;
         if ((rc = fetch_counters(c)) != NKML_OK) return rc; // the one wait of the batch
         if ((rc = collect_partition_timing(c)) != NKML_OK) return rc;
