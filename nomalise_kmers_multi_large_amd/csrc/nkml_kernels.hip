@@ -1809,13 +1809,14 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
         hipLaunchKernelGGL((k_pt_count_bucket<uint8_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
                            (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
+    hipLaunchKernelGGL(k_pt_tally_reduce, (uint32_t)((buckets + 1023) / 1024 < 64 ? (buckets + 1023) / 1024 : 64), 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
+    const uint32_t big_group = buckets >= 256 * 1024 ? 256u : buckets >= 2048 ? (uint32_t)(buckets / 1024) : 1u;
     if (c->pt_wide)
-        hipLaunchKernelGGL((k_pt_count_bucket_big<uint16_t>), (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
-                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+        hipLaunchKernelGGL((k_pt_count_bucket_big<uint16_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr, (uint32_t)buckets, big_group);
     else
-        hipLaunchKernelGGL((k_pt_count_bucket_big<uint8_t>), (uint32_t)buckets, 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
-                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr);
+        hipLaunchKernelGGL((k_pt_count_bucket_big<uint8_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr, (uint32_t)buckets, big_group);
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
         hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
@@ -2040,7 +2041,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
 #ifdef HB_STAMP
     hipLaunchKernelGGL(k_hb_stamp_print, 1, 1, 0, c->stream);
 #endif
-    hipLaunchKernelGGL(k_pt_tally_reduce, 1, 1024, 0, c->stream, c->pt_tally, n_ranges, c->d_ctr);
+    hipLaunchKernelGGL(k_pt_tally_reduce, (n_ranges + 1023) / 1024 < 64 ? (n_ranges + 1023) / 1024 : 64, 1024, 0, c->stream, c->pt_tally, n_ranges, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     if (!seeding) {
         hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
