@@ -1184,6 +1184,38 @@ __global__ void __launch_bounds__(256) k_dump_hashed(const Slot *__restrict__ sl
     }
 }
 
+// The partition passes and the bucket kernels take stream-order ranks from returning LDS adds: lanes of one wavefront
+// instruction that meet at an address are served in ascending lane order (measured on gfx950 over 5e10 adds with 1 to 16
+// wavefronts per workgroup, tools/microbench/lds_atomic_order.hip; not a documented guarantee).  This kernel checks that on
+// the device at hand before a partitioned context is created: every lane adds to one of `spread` counters and compares what
+// it gets back with the count before the round plus the lanes below it that chose the same counter.
+__global__ void __launch_bounds__(1024) k_lds_order_check(uint32_t *bad)
+{
+    __shared__ uint32_t cnt[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t nbad = 0;
+    for (uint32_t spread = 1; spread <= 64; spread <<= 1) {
+        cnt[wv][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t r = 0; r < 64; r++) {
+            uint32_t h = (blockIdx.x * 16u + wv) * 0x9E3779B1u ^ (r * 64u + lane) * 0x85ebca6bu ^ spread;
+            h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
+            const uint32_t d = h & (spread - 1);
+            const uint32_t before = __hip_atomic_load(&cnt[wv][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t got = atomicAdd(&cnt[wv][d], 1u);
+            uint32_t below = 0;
+            for (int b = 0; b < 64; b++) {
+                const uint32_t db = __shfl(d, b);
+                below += (b < lane && db == d) ? 1u : 0u;
+            }
+            nbad += got != before + below ? 1u : 0u;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 } // namespace
 
 // ======================================================================================================
@@ -1197,6 +1229,7 @@ __global__ void __launch_bounds__(256) k_dump_hashed(const Slot *__restrict__ sl
 static __device__ __align__(256) uint32_t scratch[2 * (NKML_ROUTE_STATIC_ENTRIES + 64) + 2048];
 constexpr int MAX_DEVICES = 64;
 static uint32_t *g_scratch_ptr[MAX_DEVICES]; // device address of `scratch` on each device, null until first asked for
+static int g_lds_order[MAX_DEVICES];         // k_lds_order_check on each device: 0 not run yet, 1 passed, -1 failed
 
 struct nkml_ctx {
     nkml_config cfg;
@@ -2247,6 +2280,24 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         void *p = nullptr;
         CREATE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         g_scratch_ptr[cfg->device] = static_cast<uint32_t *>(p);
+    }
+    if (c->partitioned) {
+        // stream-order ranks come from returning LDS adds: make sure this device serves them in lane order
+        int &state = g_lds_order[cfg->device < MAX_DEVICES ? cfg->device : MAX_DEVICES - 1];
+        if (state == 0 || cfg->device >= MAX_DEVICES) {
+            uint32_t bad = 0;
+            CREATE_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+            hipLaunchKernelGGL(k_lds_order_check, 32, 1024, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
+            CREATE_HIP(hipGetLastError());
+            CREATE_HIP(hipMemcpyAsync(&bad, c->d_ctr, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+            CREATE_HIP(hipStreamSynchronize(c->stream));
+            state = bad ? -1 : 1;
+        }
+        if (state < 0) {
+            *out = c;
+            return fail(c, NKML_E_NODEVICE, "this device does not serve returning LDS adds of one instruction in lane order: "
+                                            "the partitioned counting paths cannot rank here (NKML_F_COUNT_ATOMIC selects the other path)");
+        }
     }
     CREATE_CHK(alloc_table(c));
     CREATE_HIP(hipMalloc(&c->d_seq, npos + 64));
