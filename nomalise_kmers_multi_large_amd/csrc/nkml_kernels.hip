@@ -1197,7 +1197,7 @@ __global__ void __launch_bounds__(1024) k_lds_order_check(uint32_t *bad)
     for (uint32_t spread = 1; spread <= 64; spread <<= 1) {
         cnt[wv][lane] = 0;
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t r = 0; r < 64; r++) {
+        for (uint32_t r = 0; r < 16; r++) {
             uint32_t h = (blockIdx.x * 16u + wv) * 0x9E3779B1u ^ (r * 64u + lane) * 0x85ebca6bu ^ spread;
             h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
             const uint32_t d = h & (spread - 1);
@@ -1248,7 +1248,7 @@ struct nkml_ctx {
     bool partitioned;
     bool pt_wide;           // two-byte table entries (depth > 127)
     void *pt_table;
-    uint32_t *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad;
+    uint32_t *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad, *pt_bounds;
     uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
     uint16_t *pt_keysB;
@@ -1418,6 +1418,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_scanB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_startB, 260 * sizeof(uint32_t)));
+        if (!c->hashpart) HIPCHK(c, hipMalloc(&c->pt_bounds, ((c->capacity >> PT_LOWBITS) + 2) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_tally, (c->hashpart ? (uint64_t)HP_MAX_GRID : (c->capacity >> PT_LOWBITS) + 1) * sizeof(uint4)));
         HIPCHK(c, hipMalloc(&c->pt_totals, 256 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_chunks, 256 * ((c->pt_tiles_b + 1 + PT_CH - 1) / PT_CH + 1) * sizeof(uint32_t)));
@@ -1835,11 +1836,12 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     const uint32_t depth = (uint32_t)c->cfg.depth;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_pt_bucket_bounds, (uint32_t)(buckets / 256 + 1), 256, 0, c->stream, c->pt_scanB, c->pt_pad, (uint32_t)buckets, c->pt_bounds);
     if (c->pt_wide)
-        hipLaunchKernelGGL((k_pt_count_bucket<uint16_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+        hipLaunchKernelGGL((k_pt_count_bucket<uint16_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_bounds,
                            (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
     else
-        hipLaunchKernelGGL((k_pt_count_bucket<uint8_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
+        hipLaunchKernelGGL((k_pt_count_bucket<uint8_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_bounds,
                            (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
     if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     hipLaunchKernelGGL(k_pt_tally_reduce, (uint32_t)((buckets + 1023) / 1024 < 64 ? (buckets + 1023) / 1024 : 64), 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
@@ -2287,7 +2289,7 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         if (state == 0 || cfg->device >= MAX_DEVICES) {
             uint32_t bad = 0;
             CREATE_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
-            hipLaunchKernelGGL(k_lds_order_check, 32, 1024, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
+            hipLaunchKernelGGL(k_lds_order_check, 8, 1024, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
             CREATE_HIP(hipGetLastError());
             CREATE_HIP(hipMemcpyAsync(&bad, c->d_ctr, sizeof bad, hipMemcpyDeviceToHost, c->stream));
             CREATE_HIP(hipStreamSynchronize(c->stream));
@@ -2328,7 +2330,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->counts); hipFree(c->sat); hipFree(c->extra); hipFree(c->filter); hipFree(c->slots); hipFree(c->spare_slots);
     hipFree(c->hp_table); hipFree(c->hp_keysA); hipFree(c->hp_keysB); hipFree(c->hp_done);
     hipFree(c->pt_table); hipFree(c->pt_keysA); hipFree(c->pt_keysB); hipFree(c->pt_flagsA);
-    hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad);
+    hipFree(c->pt_flagsB); hipFree(c->pt_histA); hipFree(c->pt_scanA); hipFree(c->pt_histB); hipFree(c->pt_scanB); hipFree(c->pt_pad); hipFree(c->pt_bounds);
     hipFree(c->pt_tally); hipFree(c->pt_chunks); hipFree(c->pt_totals); hipFree(c->pt_startB); hipFree(c->pt_sposA); hipFree(c->pt_sposB);
     hipFree(c->d_seq); hipFree(c->d_offsets); hipFree(c->d_packed); hipFree(c->d_startbits);
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
