@@ -1359,7 +1359,7 @@ uint64_t default_hashed_capacity(int memory_gb)
 
 constexpr int HP_MAX_LOG2_BUCKET = 16;                                        // 2^32 slots = 32 GiB of table
 constexpr uint32_t HP_MAX_GRID = 65536u << HB_MAX_SUBS_LOG2;                  // sub-ranges of all buckets at most
-constexpr int HP_DEFAULT_LOG2_LOCAL = 13;                                     // 8192 slots x 12 bytes of LDS per bucket workgroup (measured best: 13 > 12 > 11)
+constexpr int HP_DEFAULT_LOG2_LOCAL = 12;                                     // 4096 slots x 12 bytes of LDS per bucket workgroup: three workgroups of 512 lanes per CU (measured: 12 > 13 > 11)
 
 // sub-range geometry of a table with 2^log2_bucket slots per bucket
 HpGeom hp_geom(const nkml_ctx *c, int log2_bucket);
