@@ -982,6 +982,7 @@ __global__ void __launch_bounds__(256) k_decide(const int32_t *__restrict__ high
 // of the same shard in the tile), computed with ballots.  Zero keys (no k-mer) are not sent.
 // ------------------------------------------------------------------------------------------------------
 constexpr int ROUTE_TILE = 1024;
+constexpr uint32_t ROUTE_BALLOT_SHARDS = 2; // up to here a ballot per shard and round ranks the keys, beyond it LDS adds do
 
 __host__ __device__ __forceinline__ uint32_t owner_of(unsigned long long key, uint32_t n_shards)
 {
@@ -1028,7 +1029,7 @@ __device__ __forceinline__ unsigned long long route_key(const RouteSource &src, 
 }
 
 template <typename KEY, int SRC>
-__global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves,
+__global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves, int use_adds,
                                                      uint32_t *__restrict__ hist)
 {
     __shared__ KEY stage[SRC != 0 ? 4 : 1][SRC != 0 ? ROUTE_STAGE : 1];
@@ -1039,19 +1040,32 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
     int lane = threadIdx.x & 63;
     uint64_t base = wv * ROUTE_TILE;
     uint32_t mine = 0; // lane sh accumulates the count of shard sh (n_shards <= 64: one lane each)
-    for (int it = 0; it < ROUTE_TILE / 64; it++) {
-        unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
-        uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
-        for (uint32_t sh = 0; sh < n_shards; sh++) {
-            unsigned long long m = __ballot(own == sh);
-            if ((uint32_t)lane == sh) mine += (uint32_t)__popcll(m);
+    if (use_adds) {
+        // many shards: one LDS add per key instead of a ballot per shard and round
+        __shared__ uint32_t cnt[4][64];
+        uint32_t *my = cnt[threadIdx.x >> 6];
+        my[lane] = 0; // the wavefront's own row: its LDS instructions run in order
+        for (int it = 0; it < ROUTE_TILE / 64; it++) {
+            unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+            if (key) atomicAdd(&my[owner_of(key, n_shards)], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        mine = __hip_atomic_load(&my[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        for (int it = 0; it < ROUTE_TILE / 64; it++) {
+            unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+            uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
+            for (uint32_t sh = 0; sh < n_shards; sh++) {
+                unsigned long long m = __ballot(own == sh);
+                if ((uint32_t)lane == sh) mine += (uint32_t)__popcll(m);
+            }
         }
     }
     if ((uint32_t)lane < n_shards) hist[(uint64_t)lane * n_waves + wv] = mine;
 }
 
 template <typename KEY, int SRC>
-__global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves,
+__global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves, int use_adds,
                                                        const uint32_t *__restrict__ offsets, KEY *__restrict__ send_keys,
                                                        uint32_t *__restrict__ send_src)
 {
@@ -1063,6 +1077,24 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
     int lane = threadIdx.x & 63;
     uint64_t base = wv * ROUTE_TILE;
     uint32_t next = (uint32_t)lane < n_shards ? offsets[(uint64_t)lane * n_waves + wv] : 0u; // lane sh: next free slot of shard sh
+    if (use_adds) {
+        // many shards: the next free slot of every shard sits in LDS and a key takes its place with one returning add - the
+        // lanes of one instruction that meet at an address are served in lane order, a wavefront's LDS instructions in
+        // program order, so the places follow the tile's stream order (k_lds_order_check vouches for the device)
+        __shared__ uint32_t slot[4][64];
+        uint32_t *my = slot[threadIdx.x >> 6];
+        my[lane] = next;
+        for (int it = 0; it < ROUTE_TILE / 64; it++) {
+            uint64_t i = base + it * 64 + lane;
+            unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+            if (key) {
+                const uint32_t dst = atomicAdd(&my[owner_of(key, n_shards)], 1u);
+                send_keys[dst] = (KEY)key;
+                send_src[dst] = (uint32_t)i;
+            }
+        }
+        return;
+    }
     for (int it = 0; it < ROUTE_TILE / 64; it++) {
         uint64_t i = base + it * 64 + lane;
         unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
@@ -2283,8 +2315,9 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         CREATE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         g_scratch_ptr[cfg->device] = static_cast<uint32_t *>(p);
     }
-    if (c->partitioned) {
-        // stream-order ranks come from returning LDS adds: make sure this device serves them in lane order
+    {
+        // stream-order ranks come from returning LDS adds (partitioned counting, routing to more than two shards): make sure
+        // this device serves them in lane order
         int &state = g_lds_order[cfg->device < MAX_DEVICES ? cfg->device : MAX_DEVICES - 1];
         if (state == 0 || cfg->device >= MAX_DEVICES) {
             uint32_t bad = 0;
@@ -2295,7 +2328,7 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
             CREATE_HIP(hipStreamSynchronize(c->stream));
             state = bad ? -1 : 1;
         }
-        if (state < 0) {
+        if (state < 0 && c->partitioned) {
             *out = c;
             return fail(c, NKML_E_NODEVICE, "this device does not serve returning LDS adds of one instruction in lane order: "
                                             "the partitioned counting paths cannot rank here (NKML_F_COUNT_ATOMIC selects the other path)");
@@ -2696,8 +2729,10 @@ static int route_run(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t 
     HIPCHK(c, hipMemsetAsync(hist + entries, 0, sizeof(uint32_t), c->stream)); // one extra entry: the scan's last output = total
     RouteSource src = {d_keys, c->d_packed, c->d_startbits, n_bases, c->cfg.ksize};
     const int mode = d_keys ? 0 : c->cfg.canonical ? 2 : 1;
-#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, hist)
-#define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, off, \
+    // beyond two shards one LDS add per key ranks it (where the device serves such adds in lane order: checked at nkml_create)
+    const int use_adds = n_shards > ROUTE_BALLOT_SHARDS && c->cfg.device < MAX_DEVICES && g_lds_order[c->cfg.device] > 0;
+#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, hist)
+#define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, off, \
                                                    (KEY *)d_send_keys, d_send_src)
 #define ROUTE_DISPATCH(WHAT)                                                                                      \
     do {                                                                                                          \
