@@ -106,7 +106,10 @@ const char *nkml_strerror(int code);
 const char *nkml_last_error(const nkml_ctx *ctx);
 
 /* Life cycle.  Replaces init_hash_table / destroy_hash_table (ref:881-906) and the per-run table of ref:2279.
- * Fails with NKML_E_NODEVICE when no gfx950 device is present: there is no CPU fallback. */
+ * Fails with NKML_E_NODEVICE when no gfx950 device is present: there is no CPU fallback.  The partitioned counting paths
+ * take stream-order ranks from returning LDS adds, which the device has to serve in lane order within one instruction;
+ * nkml_create checks that once per device (under a millisecond) and refuses a partitioned context with NKML_E_NODEVICE
+ * and a message in nkml_last_error() if the check fails (NKML_F_COUNT_ATOMIC selects the path that does not need it). */
 int nkml_create(const nkml_config *cfg, nkml_ctx **out);
 void nkml_destroy(nkml_ctx *ctx);
 /* Forget every count (a fresh run on the same context). */
