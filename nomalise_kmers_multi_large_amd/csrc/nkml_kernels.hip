@@ -1280,7 +1280,8 @@ struct nkml_ctx {
     bool partitioned;
     bool pt_wide;           // two-byte table entries (depth > 127)
     void *pt_table;
-    uint32_t *pt_keysA, *pt_histA, *pt_scanA, *pt_histB, *pt_scanB, *pt_pad, *pt_bounds;
+    uint32_t *pt_keysA, *pt_scanA, *pt_scanB, *pt_pad, *pt_bounds;
+    pt_hist_t *pt_histA, *pt_histB;
     uint4 *pt_tally;                             // per bucket: new k-mers, keys counted, keys of saturated k-mers
     uint32_t *pt_chunks, *pt_totals, *pt_startB; // column-scan scratch, keys per digit, group starts of the second pass
     uint16_t *pt_keysB;
@@ -1444,9 +1445,9 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_sposA, c->pt_tiles_a * PT_TILE / 8 * 3 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_sposB, na / 8 * 3 * sizeof(uint32_t)));
         // histograms and their scans: one row of 256 per tile plus the all-zero row after the last tile
-        HIPCHK(c, hipMalloc(&c->pt_histA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_histA, 256 * (c->pt_tiles_a + 1) * sizeof(pt_hist_t)));
         HIPCHK(c, hipMalloc(&c->pt_scanA, 256 * (c->pt_tiles_a + 1) * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&c->pt_histB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_histB, 256 * (c->pt_tiles_b + 1) * sizeof(pt_hist_t)));
         HIPCHK(c, hipMalloc(&c->pt_scanB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_startB, 260 * sizeof(uint32_t)));
@@ -1830,8 +1831,8 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
     const int shift_a = PT_LOWBITS, shift_b = PT_LOWBITS + 8;
     const uint32_t *n_a = c->pt_pad + 256;                 // padded length of the first pass's output, on the device
-    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     const uint64_t n_words = n / 16;
     const int k = c->cfg.ksize;
@@ -2006,7 +2007,8 @@ int hp_leave(nkml_ctx *c)
     c->hp_keysA = c->hp_keysB = nullptr;
     c->hp_done = nullptr;
     c->pt_flagsA = c->pt_flagsB = nullptr;
-    c->pt_sposA = c->pt_sposB = c->pt_histA = c->pt_scanA = c->pt_histB = c->pt_scanB = c->pt_pad = c->pt_startB = c->pt_totals = c->pt_chunks = nullptr;
+    c->pt_sposA = c->pt_sposB = c->pt_scanA = c->pt_scanB = c->pt_pad = c->pt_startB = c->pt_totals = c->pt_chunks = nullptr;
+    c->pt_histA = c->pt_histB = nullptr;
     c->pt_tally = nullptr;
     c->slots = ns;
     c->filter = filter;
@@ -2052,8 +2054,8 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     const uint64_t ta = (n + PT_TILE - 1) / PT_TILE, tb = ta + 256 + 1, ra = ta + 1, rb = tb + 1;
     const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
     const uint32_t *n_a = c->pt_pad + 256;
-    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     const uint64_t n_words = n / 16;
     const int k = c->cfg.ksize;
