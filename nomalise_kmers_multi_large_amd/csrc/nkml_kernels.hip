@@ -1846,7 +1846,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     hipLaunchKernelGGL(k_pt_colsum, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, ca, c->pt_totals);
     hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 1, c->pt_pad);
-    hipLaunchKernelGGL(k_pt_rowscan, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks, c->pt_pad, c->pt_scanA);
+    hipLaunchKernelGGL(k_pt_rowscan, ca, PT_ROWSCAN_THREADS, 0, c->stream, c->pt_histA, ra, c->pt_chunks, c->pt_pad, c->pt_scanA);
     hipLaunchKernelGGL(k_pt_zero_gaps, 256, 256, 0, c->stream, c->pt_totals, c->pt_pad, c->pt_keysA);
     const uint32_t ga = (uint32_t)((ta + 7) / 8 * 8), gb = (uint32_t)((tb + 7) / 8 * 8);
     if (d_keys)
@@ -1862,7 +1862,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     hipLaunchKernelGGL(k_pt_colsum, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, cb, c->pt_totals);
     hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 0, c->pt_startB);
-    hipLaunchKernelGGL(k_pt_rowscan, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
+    hipLaunchKernelGGL(k_pt_rowscan, cb, PT_ROWSCAN_THREADS, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
     hipLaunchKernelGGL((k_pt_scatter<uint16_t>), gb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, c->pt_scanB,
                        c->pt_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
@@ -2069,7 +2069,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     hipLaunchKernelGGL(k_pt_colsum, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, ca, c->pt_totals);
     hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 1, c->pt_pad);
-    hipLaunchKernelGGL(k_pt_rowscan, ca, 256, 0, c->stream, c->pt_histA, ra, c->pt_chunks, c->pt_pad, c->pt_scanA);
+    hipLaunchKernelGGL(k_pt_rowscan, ca, PT_ROWSCAN_THREADS, 0, c->stream, c->pt_histA, ra, c->pt_chunks, c->pt_pad, c->pt_scanA);
     hipLaunchKernelGGL(k_hp_zero_gaps, 256, 256, 0, c->stream, c->pt_totals, c->pt_pad, c->hp_keysA);
     const uint32_t ga = (uint32_t)((ta + 7) / 8 * 8), gb = (uint32_t)((tb + 7) / 8 * 8);
     if (d_keys)
@@ -2082,7 +2082,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     hipLaunchKernelGGL(k_pt_colsum, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks);
     hipLaunchKernelGGL(k_pt_chunkscan, 256, 256, 0, c->stream, c->pt_chunks, cb, c->pt_totals);
     hipLaunchKernelGGL(k_pt_starts, 1, 256, 0, c->stream, c->pt_totals, 0, c->pt_startB);
-    hipLaunchKernelGGL(k_pt_rowscan, cb, 256, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
+    hipLaunchKernelGGL(k_pt_rowscan, cb, PT_ROWSCAN_THREADS, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
     hipLaunchKernelGGL((k_hp_scatter<false>), gb, PT_THREADS, 0, c->stream, c->hp_keysA, (uint64_t)0, n_a, HP_SHIFT_B, c->pt_scanB, c->hp_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
     {
