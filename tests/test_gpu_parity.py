@@ -984,3 +984,37 @@ def o_unique_after_seeding(oracle_lib, k, depth, canonical, seeds):
     for r in seeds:
         o.seed(r)
     return o.unique
+
+
+@pytest.mark.gpu
+def test_a_device_that_fails_the_lds_order_check_gets_no_partitioned_context():
+    """The partitioned paths rank with returning LDS adds; nkml_create checks the device's order once and refuses a
+    partitioned context if it fails, while the atomic path (and routing, which falls back to ballots) still work and agree
+    with the oracle.  NKML_TEST_LDS_DISORDER makes the check fail; a process of its own, as the result is kept per device."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import nomalise_kmers_multi_large_amd as nk
+from nomalise_kmers_multi_large_amd import binding as B, synth
+from tests.helpers import Oracle
+try:
+    nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=4096, max_batch_bases=4096 * 150)
+    print("CREATED")
+except Exception as e:
+    print("REFUSED", "lane order" in str(e))
+c1, c2 = next(synth.pair_blocks(1000, seed=3, transcripts=4, block=1000))
+seq, off = synth.interleave(c1, c2)
+o = Oracle(15, 20, False)
+want_h, want_t = o.batch(seq, off)
+with nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=4096, max_batch_bases=4096 * 150, flags=B.NKML_F_COUNT_ATOMIC) as g:
+    h, t = g.process_batch(seq, off)
+    print("ATOMIC", bool(np.array_equal(h, want_h) and np.array_equal(t, want_t)))
+'''
+    env = dict(os.environ, NKML_TEST_LDS_DISORDER="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert "REFUSED True" in out.stdout, out.stdout + out.stderr
+    assert "ATOMIC True" in out.stdout, out.stdout + out.stderr
