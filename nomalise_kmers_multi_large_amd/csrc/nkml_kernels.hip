@@ -81,8 +81,12 @@ __global__ void __launch_bounds__(256) k_mark_starts(const uint64_t *__restrict_
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i > n_reads) return;
-    uint64_t p = offsets[i];
-    atomicOr(&startbits[p >> 4], 1u << (p & 15));
+    const uint64_t p = offsets[i];
+    // A start whose neighbours are 16 or more positions away has its word of 16 positions to itself (the words were
+    // cleared before): a plain store.  Reads shorter than a word share words and take turns with an atomic.
+    const bool alone = (i == 0 || p - offsets[i - 1] >= 16) && (i == n_reads || offsets[i + 1] - p >= 16);
+    if (alone) startbits[p >> 4] = 1u << (p & 15);
+    else atomicOr(&startbits[p >> 4], 1u << (p & 15));
 }
 
 // ------------------------------------------------------------------------------------------------------
