@@ -1082,20 +1082,50 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
     uint64_t base = wv * ROUTE_TILE;
     uint32_t next = (uint32_t)lane < n_shards ? offsets[(uint64_t)lane * n_waves + wv] : 0u; // lane sh: next free slot of shard sh
     if (use_adds) {
-        // many shards: the next free slot of every shard sits in LDS and a key takes its place with one returning add - the
-        // lanes of one instruction that meet at an address are served in lane order, a wavefront's LDS instructions in
-        // program order, so the places follow the tile's stream order (k_lds_order_check vouches for the device)
-        __shared__ uint32_t slot[4][64];
-        uint32_t *my = slot[threadIdx.x >> 6];
-        my[lane] = next;
+        // many shards: the tile's keys are first brought into shard order inside LDS - counts per shard, their prefix, then
+        // every key takes the next place of its shard with one returning add (the lanes of one instruction that meet at an
+        // address are served in lane order, a wavefront's LDS instructions in program order, so the places follow the tile's
+        // stream order; k_lds_order_check vouches for the device) - and leave as one run per shard: neighbouring lanes write
+        // neighbouring addresses instead of a few keys here and a few there.
+        __shared__ uint32_t cnt[4][64], gdst[4][64];
+        __shared__ uint16_t meta[4][ROUTE_TILE];                                  // element of the tile (10 bits) and shard (6 bits) per place
+        __shared__ KEY obuf[SRC != 0 ? 1 : 4][SRC != 0 ? 1 : ROUTE_TILE];         // SRC != 0: the staging area is free once the keys are in registers
+        const int w = threadIdx.x >> 6;
+        KEY *okey = SRC != 0 ? stage[w] : obuf[SRC != 0 ? 0 : w];
+        uint32_t *my = cnt[w];
+        KEY kk[ROUTE_TILE / 64];
+#pragma unroll
+        for (int it = 0; it < ROUTE_TILE / 64; it++) kk[it] = (KEY)route_key<KEY, SRC>(src, stage[SRC != 0 ? w : 0], base, it, lane, n);
+        my[lane] = 0; // the wavefront's own row: its LDS instructions run in order
+#pragma unroll
+        for (int it = 0; it < ROUTE_TILE / 64; it++)
+            if (kk[it]) atomicAdd(&my[owner_of(kk[it], n_shards)], 1u);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t c = __hip_atomic_load(&my[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        gdst[w][lane] = next - (incl - c);   // place i of the tile's shard order goes to gdst[shard] + i
+        __builtin_amdgcn_wave_barrier();
+        my[lane] = incl - c;                 // the shard's first place
+#pragma unroll
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
-            uint64_t i = base + it * 64 + lane;
-            unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
-            if (key) {
-                const uint32_t dst = atomicAdd(&my[owner_of(key, n_shards)], 1u);
-                send_keys[dst] = (KEY)key;
-                send_src[dst] = (uint32_t)i;
+            if (kk[it]) {
+                const uint32_t own = owner_of(kk[it], n_shards);
+                const uint32_t at = atomicAdd(&my[own], 1u);
+                okey[at] = kk[it];
+                meta[w][at] = (uint16_t)((uint32_t)(it * 64 + lane) | (own << 10));
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t at = lane; at < total; at += 64) {
+            const uint32_t m = meta[w][at], dst = gdst[w][m >> 10] + at;
+            send_keys[dst] = okey[at];
+            send_src[dst] = (uint32_t)(base + (m & 1023u));
         }
         return;
     }

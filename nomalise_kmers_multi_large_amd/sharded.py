@@ -80,7 +80,8 @@ class HipShardEngine:
         """recv_keys: what recv_buffer returned, filled (the buffer behind it is padded to a multiple of 16 keys here)."""
         n = recv_keys.numel()
         n16 = (n + 15) // 16 * 16
-        whole = next(b for b in self.recv_keys2 if b.data_ptr() == recv_keys.data_ptr()) if n else self.recv_keys
+        # a world of one counts its keys where routing left them: the send buffers are candidates too
+        whole = next(b for b in self.recv_keys2 + self.send_keys2 if b.data_ptr() == recv_keys.data_ptr()) if n else self.recv_keys
         if n16 > n:
             whole[n:n16].zero_()
         self.nk.count_keys_device(whole.data_ptr(), n16, self.recv_flags.data_ptr())
@@ -270,8 +271,12 @@ class ShardedNormaliser:
             if too_many:
                 raise RuntimeError("received %d keys, more than the %d this rank was sized for" % (sum(x["recv_counts"]), eng.cap))
             raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or more keys than it was sized for)")
-        x["recv_keys"] = eng.recv_buffer(sum(x["recv_counts"]))
-        x["owed"] = self._all_to_all_start(x["recv_keys"], send_keys, x["recv_counts"], x["send_counts"], x["peak"])
+        if W == 1 and hasattr(eng, "kmerise_route"):
+            # nothing has to travel: the only segment is this rank's own, and it is counted where routing left it
+            x["recv_keys"], x["owed"] = send_keys, []
+        else:
+            x["recv_keys"] = eng.recv_buffer(sum(x["recv_counts"]))
+            x["owed"] = self._all_to_all_start(x["recv_keys"], send_keys, x["recv_counts"], x["send_counts"], x["peak"])
         x["alive"] = (send_keys, seq, offsets)
         return x
 
@@ -297,8 +302,11 @@ class ShardedNormaliser:
         except Exception as e:   # e.g. the table shard cannot grow any further
             err = e
         self._agree(err, seq)
-        back = eng.back_buffer(sum(x["send_counts"]))
-        self._all_to_all(back, recv_flags, x["send_counts"], x["recv_counts"], x["peak"])
+        if W == 1 and hasattr(eng, "kmerise_route"):
+            back = recv_flags
+        else:
+            back = eng.back_buffer(sum(x["send_counts"]))
+            self._all_to_all(back, recv_flags, x["send_counts"], x["recv_counts"], x["peak"])
         flags = eng.unroute(back, x["send_src"], x["n_positions"])
         high, total = eng.reduce(flags, offsets, n_reads)
         gathered = None
