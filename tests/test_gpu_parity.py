@@ -1018,3 +1018,31 @@ with nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=4096, max_batch_bases
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert "REFUSED True" in out.stdout, out.stdout + out.stderr
     assert "ATOMIC True" in out.stdout, out.stdout + out.stderr
+
+
+# ---- routing on its own: the whole output against a stable partition computed with numpy ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [15, 25])
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8, 64])
+def test_route_keys_is_the_stable_partition_by_owner(nk, k, n_shards):
+    import torch
+    rng = np.random.default_rng(40 + k + n_shards)
+    with nk.KmerNormaliser(k, 10, 0.9, False, device=0, max_batch_reads=1 << 16, max_batch_bases=1 << 22) as g:
+        wide = g.key_bytes == 8
+        dt_np, dt_t = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
+        for n in (16, 1024 * 37 + 16, 1 << 20):   # less than a tile, ragged last tile, many tiles
+            keys = rng.integers(1, (1 << (2 * k)) - 1 if wide else (1 << 30) - 1, n, dtype=np.int64)
+            keys[rng.random(n) < 0.15] = 0                      # positions without a k-mer are not sent
+            keys[n // 3: n // 3 + min(n // 4, 3000)] = keys[0]  # a long run of one owner inside the tiles it covers
+            keys_t = torch.from_numpy(keys.astype(dt_np)).cuda()
+            send_keys = torch.full((n,), -1, dtype=dt_t, device="cuda")
+            send_src = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+            counts = g.route_keys_device(keys_t.data_ptr(), n, n_shards, send_keys.data_ptr(), send_src.data_ptr())
+            g.synchronize()
+            own = ((((keys.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)) * np.uint64(n_shards)) >> np.uint64(32)).astype(np.int64)
+            own[keys == 0] = n_shards
+            order = np.argsort(own, kind="stable")[: int((keys != 0).sum())]
+            assert counts == [int((own == s).sum()) for s in range(n_shards)]
+            np.testing.assert_array_equal(send_src[: len(order)].cpu().numpy(), order.astype(np.int32))
+            np.testing.assert_array_equal(send_keys[: len(order)].cpu().numpy(), keys[order].astype(dt_np))
+            assert int(send_src[len(order):].max().item()) == -1 if len(order) < n else True   # nothing written past the end
