@@ -1045,16 +1045,19 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
     uint64_t base = wv * ROUTE_TILE;
     uint32_t mine = 0; // lane sh accumulates the count of shard sh (n_shards <= 64: one lane each)
     if (use_adds) {
-        // many shards: one LDS add per key instead of a ballot per shard and round
+        // many shards: one LDS add per key instead of a ballot per shard and round.  Order does not matter for a count, so
+        // a shard's counter is spread over `ways` addresses picked by the lane: fewer lanes of an instruction meet at one.
         __shared__ uint32_t cnt[4][64];
         uint32_t *my = cnt[threadIdx.x >> 6];
+        const uint32_t lg = 31u - (uint32_t)__builtin_clz(64u / n_shards), way = (uint32_t)lane & ((1u << lg) - 1u);
         my[lane] = 0; // the wavefront's own row: its LDS instructions run in order
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
             unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
-            if (key) atomicAdd(&my[owner_of(key, n_shards)], 1u);
+            if (key) atomicAdd(&my[(owner_of(key, n_shards) << lg) | way], 1u);
         }
         __builtin_amdgcn_wave_barrier();
-        mine = __hip_atomic_load(&my[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)lane < n_shards)
+            for (uint32_t j = 0; j < (1u << lg); j++) mine += __hip_atomic_load(&my[((uint32_t)lane << lg) | j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
             unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
@@ -1082,11 +1085,12 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
     uint64_t base = wv * ROUTE_TILE;
     uint32_t next = (uint32_t)lane < n_shards ? offsets[(uint64_t)lane * n_waves + wv] : 0u; // lane sh: next free slot of shard sh
     if (use_adds) {
-        // many shards: the tile's keys are first brought into shard order inside LDS - counts per shard, their prefix, then
-        // every key takes the next place of its shard with one returning add (the lanes of one instruction that meet at an
-        // address are served in lane order, a wavefront's LDS instructions in program order, so the places follow the tile's
-        // stream order; k_lds_order_check vouches for the device) - and leave as one run per shard: neighbouring lanes write
-        // neighbouring addresses instead of a few keys here and a few there.
+        // many shards: the tile's keys are first brought into shard order inside LDS and leave as one run per shard, so that
+        // neighbouring lanes write neighbouring addresses instead of a few keys here and a few there.  One returning add per
+        // key on its shard's counter gives the key's rank among the tile's keys of that shard (the lanes of one instruction
+        // that meet at an address are served in lane order, a wavefront's LDS instructions in program order, so the ranks
+        // follow the tile's stream order; k_lds_order_check vouches for the device) and leaves the shard's count behind; the
+        // prefix of the counts turns ranks into places.
         __shared__ uint32_t cnt[4][64], gdst[4][64];
         __shared__ uint16_t meta[4][ROUTE_TILE];                                  // element of the tile (10 bits) and shard (6 bits) per place
         __shared__ KEY obuf[SRC != 0 ? 1 : 4][SRC != 0 ? 1 : ROUTE_TILE];         // SRC != 0: the staging area is free once the keys are in registers
@@ -1094,12 +1098,19 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
         KEY *okey = SRC != 0 ? stage[w] : obuf[SRC != 0 ? 0 : w];
         uint32_t *my = cnt[w];
         KEY kk[ROUTE_TILE / 64];
+        uint32_t rk[ROUTE_TILE / 128];       // per key: rank (10 bits) and shard (6 bits), two keys to a register
 #pragma unroll
         for (int it = 0; it < ROUTE_TILE / 64; it++) kk[it] = (KEY)route_key<KEY, SRC>(src, stage[SRC != 0 ? w : 0], base, it, lane, n);
         my[lane] = 0; // the wavefront's own row: its LDS instructions run in order
 #pragma unroll
-        for (int it = 0; it < ROUTE_TILE / 64; it++)
-            if (kk[it]) atomicAdd(&my[owner_of(kk[it], n_shards)], 1u);
+        for (int it = 0; it < ROUTE_TILE / 64; it++) {
+            uint32_t v = 0;
+            if (kk[it]) {
+                const uint32_t own = owner_of(kk[it], n_shards);
+                v = atomicAdd(&my[own], 1u) | (own << 10);
+            }
+            rk[it >> 1] = (it & 1) ? (rk[it >> 1] | (v << 16)) : v;
+        }
         __builtin_amdgcn_wave_barrier();
         const uint32_t c = __hip_atomic_load(&my[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t incl = c;
@@ -1112,11 +1123,12 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
         gdst[w][lane] = next - (incl - c);   // place i of the tile's shard order goes to gdst[shard] + i
         __builtin_amdgcn_wave_barrier();
         my[lane] = incl - c;                 // the shard's first place
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
             if (kk[it]) {
-                const uint32_t own = owner_of(kk[it], n_shards);
-                const uint32_t at = atomicAdd(&my[own], 1u);
+                const uint32_t v = (rk[it >> 1] >> ((it & 1) * 16)) & 0xffffu, own = v >> 10;
+                const uint32_t at = my[own] + (v & 1023u);
                 okey[at] = kk[it];
                 meta[w][at] = (uint16_t)((uint32_t)(it * 64 + lane) | (own << 10));
             }
