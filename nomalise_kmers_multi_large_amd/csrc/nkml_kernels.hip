@@ -123,11 +123,18 @@ __device__ __forceinline__ uint32_t count_bad4(uint32_t v)
     return bad;
 }
 
+// With startbits != nullptr the pass also clears the batch's start bits and the four halo words behind both arrays
+// (the grid then covers n_words + 4 words): a separate fill of the start bits took as long as the packing itself.
 __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, uint64_t n_bases,
-                                              uint32_t *__restrict__ packed, uint64_t n_words, Counters *ctr)
+                                              uint32_t *__restrict__ packed, uint64_t n_words, Counters *ctr,
+                                              uint32_t *__restrict__ startbits)
 {
     uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t bad = 0;
+    if (startbits && w < n_words + 4) {
+        startbits[w] = 0;
+        if (w >= n_words) packed[w] = 0;
+    }
     if (w < n_words) {
         uint64_t base = w * 16;
         uint32_t v[4];
@@ -153,6 +160,18 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t *__restrict__ seq, u
             bad = count_bad4(v[0]) + count_bad4(v[1]) + count_bad4(v[2]) + count_bad4(v[3]);
     }
     if (bad) atomicAdd(&ctr->bad_bases, bad);
+}
+
+// A batch that arrives packed: its words into the context's array, its start bits cleared, four zero words of halo
+// behind both - one pass instead of a fill and a copy.
+__global__ void __launch_bounds__(256) k_take_words(const uint32_t *__restrict__ src, uint64_t n_words, uint32_t *__restrict__ packed,
+                                                    uint32_t *__restrict__ startbits)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w < n_words + 4) {
+        packed[w] = w < n_words ? src[w] : 0u;
+        startbits[w] = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1580,10 +1599,8 @@ int fetch_counters(nkml_ctx *c)
 int run_prepare(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases)
 {
     uint64_t n_words = (n_bases + 15) / 16;
-    HIPCHK(c, hipMemsetAsync(c->d_startbits, 0, (n_words + 4) * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_packed + n_words, 0, 4 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_pack, blocks_for(n_words + 4), 256, 0, c->stream, d_seq, n_bases, c->d_packed, n_words, c->d_ctr, c->d_startbits);
     hipLaunchKernelGGL(k_mark_starts, blocks_for((uint64_t)n_reads + 1), 256, 0, c->stream, d_offsets, n_reads, c->d_startbits);
-    hipLaunchKernelGGL(k_pack, blocks_for(n_words), 256, 0, c->stream, d_seq, n_bases, c->d_packed, n_words, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     return NKML_OK;
 }
@@ -2611,7 +2628,7 @@ int nkml_pack_device(nkml_ctx *c, const uint8_t *d_seq, uint64_t n_bases, uint32
     if (n_bases == 0) return NKML_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint64_t n_words = (n_bases + 15) / 16;
-    hipLaunchKernelGGL(k_pack, blocks_for(n_words), 256, 0, c->stream, d_seq, n_bases, d_words, n_words, c->d_ctr);
+    hipLaunchKernelGGL(k_pack, blocks_for(n_words), 256, 0, c->stream, d_seq, n_bases, d_words, n_words, c->d_ctr, (uint32_t *)nullptr);
     HIPCHK(c, hipGetLastError());
     return NKML_OK;
 }
@@ -2625,9 +2642,7 @@ int nkml_process_packed_device(nkml_ctx *c, const uint32_t *d_words, const uint6
     if (n_reads == 0) return NKML_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint64_t n_words = (n_bases + 15) / 16;
-    HIPCHK(c, hipMemsetAsync(c->d_startbits, 0, (n_words + 4) * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_packed + n_words, 0, 4 * sizeof(uint32_t), c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_packed, d_words, n_words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_take_words, blocks_for(n_words + 4), 256, 0, c->stream, d_words, n_words, c->d_packed, c->d_startbits);
     hipLaunchKernelGGL(k_mark_starts, blocks_for((uint64_t)n_reads + 1), 256, 0, c->stream, d_offsets, n_reads, c->d_startbits);
     HIPCHK(c, hipGetLastError());
     if ((rc = hp_maybe_leave(c)) != NKML_OK) return rc;
