@@ -236,6 +236,46 @@ __device__ __forceinline__ void word_keys32(const uint32_t *__restrict__ packed,
     }
 }
 
+// Half a packed word per lane (half = 0: windows 0-7, 1: windows 8-15), for kernels whose every lane should take part;
+// the lane loads the word and its successor itself (no shuffles, so any lane may be skipped).
+template <bool CANON>
+__device__ __forceinline__ void word_keys32_half(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits, uint64_t w,
+                                                 uint32_t half, bool live, uint64_t n_bases, int k, uint32_t (&out)[8])
+{
+    if (!live) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) out[j] = 0u;
+        return;
+    }
+    const uint32_t w0 = packed[w], w1 = packed[w + 1], s0 = startbits[w], s1 = startbits[w + 1]; // 4 zero words of halo
+    const uint32_t m = (uint32_t)k - 1u;
+    uint32_t inside = 0;
+    if (m) {
+        inside = ((s0 & 0xffffu) | (s1 << 16)) >> 1;
+        uint32_t s = 1;
+        while (2 * s <= m) { inside |= inside >> s; s <<= 1; }
+        inside |= inside >> (m - s);
+    }
+    const uint64_t rem = n_bases - w * 16;
+    const uint32_t fits = rem >= (uint64_t)(15 + k) ? 0xffffu : (rem < (uint64_t)k ? 0u : (2u << (uint32_t)(rem - (uint64_t)k)) - 1u);
+    const uint32_t ok = (~inside & fits) >> (8u * half);
+    const int down = 32 - 2 * k;
+    const uint32_t mask = k == 16 ? 0xffffffffu : (1u << (2 * k)) - 1u;
+    const unsigned long long fw = ((unsigned long long)w0 << 32) | w1;
+    unsigned long long rv = 0;
+    if (CANON) rv = ((unsigned long long)reverse_pairs(~w1) << 32) | reverse_pairs(~w0);
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        const uint32_t j = 8u * half + (uint32_t)jj;
+        uint32_t code = (uint32_t)(fw >> (32u - 2u * j)) >> down;
+        if (CANON) {
+            const uint32_t rc = (uint32_t)(rv >> (2u * j)) & mask;
+            code = rc < code ? rc : code;
+        }
+        out[jj] = ((ok >> jj) & 1u) ? code : 0u;
+    }
+}
+
 template <typename KEY, bool CANON>
 __device__ __forceinline__ void word_keys(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ startbits, uint64_t w,
                                           bool live, uint64_t n_bases, int k, KEY (&out)[16])
