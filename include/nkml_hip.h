@@ -107,9 +107,14 @@ const char *nkml_last_error(const nkml_ctx *ctx);
 
 /* Life cycle.  Replaces init_hash_table / destroy_hash_table (ref:881-906) and the per-run table of ref:2279.
  * Fails with NKML_E_NODEVICE when no gfx950 device is present: there is no CPU fallback.  The partitioned counting paths
- * take stream-order ranks from returning LDS adds, which the device has to serve in lane order within one instruction;
- * nkml_create checks that once per device (under a millisecond) and refuses a partitioned context with NKML_E_NODEVICE
- * and a message in nkml_last_error() if the check fails (NKML_F_COUNT_ATOMIC selects the path that does not need it). */
+ * take stream-order ranks from returning LDS adds, which the device has to serve in lane order within one instruction
+ * (measured behaviour of gfx950, not a documented guarantee); nkml_create checks that once per device (under a
+ * millisecond, every CU as busy as the counting kernels keep it).  On a device that fails the check a context counts on
+ * the atomic path instead (one line on stderr; nkml_stats.partitioned says 0), and only a context that asks for the
+ * partitioned path with NKML_F_COUNT_PARTITIONED is refused (NKML_E_NODEVICE, message in nkml_last_error()).
+ * A context whose batch failed half-way (out of memory while the hashed table grew inside a batch, a HIP error between
+ * two kernels of a batch) holds a partly counted batch: every later submit / process / seed call on it returns
+ * NKML_E_STATE until nkml_reset. */
 int nkml_create(const nkml_config *cfg, nkml_ctx **out);
 void nkml_destroy(nkml_ctx *ctx);
 /* Forget every count (a fresh run on the same context). */
@@ -187,8 +192,10 @@ int nkml_seed_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys);
 int nkml_owner_of(uint64_t key, uint32_t n_shards);
 int nkml_route_keys_device(nkml_ctx *ctx, const void *d_keys, uint64_t n_keys, uint32_t n_shards, void *d_send_keys,
                            uint32_t *d_send_src, uint64_t *send_counts);
-/*   route_keys_static : nkml_route_keys_device for callers that cannot allocate (code under HIP graph capture, tight
- *                   serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs,
+/*   route_keys_static : nkml_route_keys_device for callers that cannot allocate (tight serving loops, harnesses that
+ *                   forbid hipMalloc).  It allocates nothing, but like nkml_route_keys_device it waits for the stream once,
+ *                   to hand the counts back in host memory - so it cannot run inside a HIP graph capture.  No counterpart
+ *                   in the reference.  Same inputs,
  *                   outputs and results as nkml_route_keys_device, but the per-tile shard counts, their scan and the scan's
  *                   block totals live in a fixed array in device memory (static, about 4 MiB per GPU, held until the
  *                   process ends) instead of buffers allocated on demand, and the call uses no allocating routine.

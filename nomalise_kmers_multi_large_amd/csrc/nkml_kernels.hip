@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include <hip/hip_runtime.h>
@@ -71,6 +72,17 @@ struct Slot {
     unsigned int state;
 };
 static_assert(sizeof(Slot) == 16, "slot layout");
+
+// Hand-over of LDS data between the lanes of ONE wavefront.  A wavefront's LDS instructions execute in program order, so
+// no barrier instruction is needed; what has to be pinned is the compiler's order: the stores before this point stay
+// before it, the loads after it stay after it, whatever their types (wave_barrier alone is a scheduling marker, not a
+// memory fence, and type-based alias analysis may otherwise move a differently typed load above the stores).
+__device__ __forceinline__ void wave_lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ------------------------------------------------------------------------------------------------------
 // K0: read starts -> startbits.  One bit per base position; a window is valid iff no read starts inside it
@@ -1114,7 +1126,7 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
             unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
             if (key) atomicAdd(&my[(owner_of(key, n_shards) << lg) | way], 1u);
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         if ((uint32_t)lane < n_shards)
             for (uint32_t j = 0; j < (1u << lg); j++) mine += __hip_atomic_load(&my[((uint32_t)lane << lg) | j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
@@ -1170,7 +1182,7 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
             }
             rk[it >> 1] = (it & 1) ? (rk[it >> 1] | (v << 16)) : v;
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         const uint32_t c = __hip_atomic_load(&my[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint32_t incl = c;
 #pragma unroll
@@ -1180,9 +1192,9 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
         }
         const uint32_t total = __shfl(incl, 63);
         gdst[w][lane] = next - (incl - c);   // place i of the tile's shard order goes to gdst[shard] + i
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         my[lane] = incl - c;                 // the shard's first place
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
 #pragma unroll
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
             if (kk[it]) {
@@ -1192,7 +1204,7 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
                 meta[w][at] = (uint16_t)((uint32_t)(it * 64 + lane) | (own << 10));
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         for (uint32_t at = lane; at < total; at += 64) {
             const uint32_t m = meta[w][at], dst = gdst[w][m >> 10] + at;
             send_keys[dst] = okey[at];
@@ -1322,34 +1334,51 @@ __global__ void __launch_bounds__(256) k_dump_hashed(const Slot *__restrict__ sl
 }
 
 // The partition passes and the bucket kernels take stream-order ranks from returning LDS adds: lanes of one wavefront
-// instruction that meet at an address are served in ascending lane order (measured on gfx950 over 5e10 adds with 1 to 16
-// wavefronts per workgroup, tools/microbench/lds_atomic_order.hip; not a documented guarantee).  This kernel checks that on
-// the device at hand before a partitioned context is created: every lane adds to one of `spread` counters and compares what
-// it gets back with the count before the round plus the lanes below it that chose the same counter.
-__global__ void __launch_bounds__(1024) k_lds_order_check(uint32_t *bad)
+// instruction that meet at an address are served in ascending lane order, and a wavefront's LDS instructions in program
+// order (measured on gfx950 over 5e10 adds with 1 to 16 wavefronts per workgroup, tools/microbench/lds_atomic_order.hip;
+// not a documented guarantee).  This kernel checks that on the device at hand before a partitioned context is created, in
+// the shape the tile kernels use it: workgroups of eight wavefronts, four of them per CU on every CU (the launch asks for
+// that many), a row of 256 counters per wavefront, eight returning adds per lane issued back to back with other LDS
+// stores and loads of the wavefront between them, digits spread over 1 to 256 counters.  Every value that comes back
+// is compared with the number of earlier elements (round, lane) of the wavefront that chose the same counter.
+constexpr int LOC_WAVES = 8, LOC_ROUNDS = 8;
+__global__ void __launch_bounds__(LOC_WAVES * 64) k_lds_order_check(uint32_t *bad)
 {
-    __shared__ uint32_t cnt[16][64];
+    __shared__ uint32_t wcnt[LOC_WAVES][256];
+    __shared__ uint32_t other[LOC_WAVES][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t nbad = 0;
-    for (uint32_t spread = 1; spread <= 64; spread <<= 1) {
-        cnt[wv][lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t r = 0; r < 16; r++) {
-            uint32_t h = (blockIdx.x * 16u + wv) * 0x9E3779B1u ^ (r * 64u + lane) * 0x85ebca6bu ^ spread;
+    uint32_t nbad = 0, sink = 0;
+    for (uint32_t spread = 1; spread <= 256; spread <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { wcnt[wv][j * 64 + lane] = 0; other[wv][j * 64 + lane] = lane; }
+        wave_lds_handover();
+        uint32_t d[LOC_ROUNDS], got[LOC_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < LOC_ROUNDS; r++) {
+            uint32_t h = (blockIdx.x * (uint32_t)LOC_WAVES + wv) * 0x9E3779B1u ^ (r * 64u + lane) * 0x85ebca6bu ^ spread;
             h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15;
-            const uint32_t d = h & (spread - 1);
-            const uint32_t before = __hip_atomic_load(&cnt[wv][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t got = atomicAdd(&cnt[wv][d], 1u);
-            uint32_t below = 0;
-            for (int b = 0; b < 64; b++) {
-                const uint32_t db = __shfl(d, b);
-                below += (b < lane && db == d) ? 1u : 0u;
-            }
-            nbad += got != before + below ? 1u : 0u;
-            __builtin_amdgcn_wave_barrier();
+            d[r] = h & (spread - 1);
         }
+#pragma unroll
+        for (int r = 0; r < LOC_ROUNDS; r++) {
+            got[r] = atomicAdd(&wcnt[wv][d[r]], 1u);
+            other[wv][(lane * 5 + r * 37) & 255] = d[r];          // unrelated stores and loads of the same wavefront in between
+            sink ^= other[wv][(lane * 3 + r * 11) & 255];
+        }
+#pragma unroll
+        for (int r = 0; r < LOC_ROUNDS; r++) {
+            uint32_t earlier = 0;
+#pragma unroll
+            for (int r2 = 0; r2 <= r; r2++)
+                for (int b = 0; b < 64; b++) {
+                    const uint32_t db = __shfl(d[r2], b);
+                    earlier += (db == d[r] && (r2 < r || b < lane)) ? 1u : 0u;
+                }
+            nbad += got[r] != earlier ? 1u : 0u;
+        }
+        wave_lds_handover();
     }
+    asm volatile("" ::"v"(sink));
     if (nbad) atomicAdd(bad, nbad);
 }
 
@@ -1367,6 +1396,7 @@ static __device__ __align__(256) uint32_t scratch[2 * (NKML_ROUTE_STATIC_ENTRIES
 constexpr int MAX_DEVICES = 64;
 static uint32_t *g_scratch_ptr[MAX_DEVICES]; // device address of `scratch` on each device, null until first asked for
 static int g_lds_order[MAX_DEVICES];         // k_lds_order_check on each device: 0 not run yet, 1 passed, -1 failed
+static std::mutex g_device_mutex;            // guards the two arrays above (contexts may be created from several threads)
 
 struct nkml_ctx {
     nkml_config cfg;
@@ -1374,6 +1404,8 @@ struct nkml_ctx {
     bool direct;
     hipStream_t stream;
     bool own_stream;
+    bool lds_ordered;       // this device passed k_lds_order_check (ranks may come from returning LDS adds)
+    bool broken;            // a batch failed after part of it had been merged into the table: unusable until nkml_reset
     char err[512];
 
     // table
@@ -1471,6 +1503,13 @@ int fail(nkml_ctx *ctx, int code, const char *fmt, ...)
         va_end(ap);
     }
     return code;
+}
+
+// A batch that fails after some of its k-mers have been merged into the table leaves counts that belong to no prefix of
+// the stream: counting on would double-count them.  Such a context answers NKML_E_STATE until nkml_reset.
+int broken_context(nkml_ctx *c)
+{
+    return fail(c, NKML_E_STATE, "an earlier batch failed half-way and left the table partly updated: nkml_reset before counting again");
 }
 
 #define HIPCHK(ctx, call)                                                                              \
@@ -1802,6 +1841,7 @@ int end_chunk(nkml_ctx *c)
 // waiting.
 int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags)
 {
+    if (c->broken) return broken_context(c);
     const uint32_t depth = (uint32_t)c->cfg.depth;
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0;
     const int exact = (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0;
@@ -1842,6 +1882,7 @@ int run_count(nkml_ctx *c, const void *d_keys, uint64_t n, uint8_t *d_flags)
 // Fused K2+K3+K4 over the prepared batch (packed words), the single-GPU path: keys live in registers only.
 int run_fused(nkml_ctx *c, uint64_t n_bases, bool seeding)
 {
+    if (c->broken) return broken_context(c);
     const uint32_t depth = (uint32_t)c->cfg.depth;
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
     const int exact = (c->cfg.flags & NKML_F_EXACT_COUNTS) ? 1 : 0;
@@ -1919,6 +1960,7 @@ int collect_partition_timing(nkml_ctx *c);
 
 int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
 {
+    if (c->broken) return broken_context(c);
     if (n == 0) return NKML_OK;
     if (c->hashpart) return run_count_hashpart(c, static_cast<const unsigned long long *>(d_keys_any), n, n_bases, d_flags, seeding);
     const uint32_t *d_keys = static_cast<const uint32_t *>(d_keys_any);
@@ -2042,17 +2084,26 @@ int hp_grow(nkml_ctx *c, bool batch_under_way)
         const uint32_t n_old = 65536u << (og.log2_bucket - og.log2_local);
         uint32_t *d2 = nullptr;
         uint4 *t2 = nullptr;
-        HIPCHK(c, hipMalloc(&d2, (uint64_t)n_old * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc(&t2, (uint64_t)n_old * sizeof(uint4)));
-        HIPCHK(c, hipMemcpyAsync(d2, c->hp_done, (uint64_t)n_old * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(t2, c->pt_tally, (uint64_t)n_old * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(k_hp_remap_done, blocks_for(n_old), 256, 0, c->stream, d2, t2, n_old, c->hp_done, c->pt_tally);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipError_t e = hipMalloc(&d2, (uint64_t)n_old * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&t2, (uint64_t)n_old * sizeof(uint4));
+        if (e == hipSuccess) e = hipMemcpyAsync(d2, c->hp_done, (uint64_t)n_old * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(t2, c->pt_tally, (uint64_t)n_old * sizeof(uint4), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_hp_remap_done, blocks_for(n_old), 256, 0, c->stream, d2, t2, n_old, c->hp_done, c->pt_tally);
+            e = hipGetLastError();
+        }
+        const hipError_t e_sync = hipStreamSynchronize(c->stream); // also on failure: nothing may still read d2 / t2 / nt
         hipFree(d2);
         hipFree(t2);
+        if (e != hipSuccess || e_sync != hipSuccess) {
+            hipFree(nt);
+            HIPCHK(c, e != hipSuccess ? e : e_sync);
+        }
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(nt); HIPCHK(c, e); }
+    }
     HIPCHK(c, hipFree(c->hp_table));
     c->hp_table = nt;
     c->capacity = ncap;
@@ -2202,6 +2253,8 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
         hipLaunchKernelGGL(k_hp_count_bucket, 65536u, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_scanB, c->pt_pad, c->hp_table, geo,
                            (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr, c->hp_keysA);
         HIPCHK(c, hipGetLastError());
+        // from here on part of the batch is in the table: a failure leaves the context unusable until nkml_reset
+        c->broken = true;
         if (profile && attempt == 0) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         if ((rc = fetch_counters(c)) != NKML_OK) return rc; // did every bucket fit?
         if (!c->h_ctr->probe_overflow) break;
@@ -2210,6 +2263,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
         c->h_ctr->probe_overflow = 0;
         if ((rc = hp_grow(c, true)) != NKML_OK) return rc;
     }
+    c->broken = false; // every sub-range of the batch is committed
 #ifdef HB_STAMP
     hipLaunchKernelGGL(k_hb_stamp_print, 1, 1, 0, c->stream);
 #endif
@@ -2414,30 +2468,39 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     CREATE_HIP(hipHostMalloc(&c->h_ctr, sizeof(Counters), hipHostMallocDefault));
     memset(c->h_ctr, 0, sizeof(Counters));
     CREATE_HIP(hipHostMalloc(&c->h_route_starts, 72 * sizeof(uint32_t), hipHostMallocDefault));
-    if (cfg->device < MAX_DEVICES && !g_scratch_ptr[cfg->device]) {
-        // this device's copy of the static scratch array (the device is current: hipSetDevice above)
-        void *p = nullptr;
-        CREATE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        g_scratch_ptr[cfg->device] = static_cast<uint32_t *>(p);
-    }
     {
+        std::lock_guard<std::mutex> lock(g_device_mutex);
+        if (cfg->device < MAX_DEVICES && !g_scratch_ptr[cfg->device]) {
+            // this device's copy of the static scratch array (the device is current: hipSetDevice above)
+            void *p = nullptr;
+            CREATE_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[cfg->device] = static_cast<uint32_t *>(p);
+        }
         // stream-order ranks come from returning LDS adds (partitioned counting, routing to more than two shards): make sure
-        // this device serves them in lane order
+        // this device serves them in lane order, with every CU as busy with such workgroups as the tile kernels keep it
         int &state = g_lds_order[cfg->device < MAX_DEVICES ? cfg->device : MAX_DEVICES - 1];
         if (state == 0 || cfg->device >= MAX_DEVICES) {
             uint32_t bad = 0;
             CREATE_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
-            hipLaunchKernelGGL(k_lds_order_check, 8, 1024, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
+            const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+            hipLaunchKernelGGL(k_lds_order_check, cus * 4u * 2u, LOC_WAVES * 64, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
             CREATE_HIP(hipGetLastError());
             CREATE_HIP(hipMemcpyAsync(&bad, c->d_ctr, sizeof bad, hipMemcpyDeviceToHost, c->stream));
             CREATE_HIP(hipStreamSynchronize(c->stream));
             state = bad ? -1 : 1;
             if (getenv("NKML_TEST_LDS_DISORDER")) state = -1; // test aid: behave like a device that fails the check
         }
+        c->lds_ordered = state > 0;
         if (state < 0 && c->partitioned) {
-            *out = c;
-            return fail(c, NKML_E_NODEVICE, "this device does not serve returning LDS adds of one instruction in lane order: "
-                                            "the partitioned counting paths cannot rank here (NKML_F_COUNT_ATOMIC selects the other path)");
+            if (cfg->flags & NKML_F_COUNT_PARTITIONED) {
+                *out = c;
+                return fail(c, NKML_E_NODEVICE, "this device does not serve returning LDS adds of one instruction in lane order: "
+                                                "the partitioned counting paths cannot rank here (NKML_F_COUNT_ATOMIC selects the other path)");
+            }
+            // not asked for by flag: count on the atomic path, whose ranks come from a sort
+            fprintf(stderr, "nkml: device %d does not serve returning LDS adds in lane order; counting on the atomic path\n", cfg->device);
+            c->partitioned = c->hashpart = false;
+            c->hp_leave_slots = 0;
         }
     }
     CREATE_CHK(alloc_table(c));
@@ -2503,6 +2566,7 @@ int nkml_reset(nkml_ctx *c)
     c->staged_pending = false;
     c->used_bound = 0;
     c->hp_unique_before = 0;
+    c->broken = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return NKML_OK;
 }
@@ -2834,7 +2898,7 @@ static int route_run(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t 
     RouteSource src = {d_keys, c->d_packed, c->d_startbits, n_bases, c->cfg.ksize};
     const int mode = d_keys ? 0 : c->cfg.canonical ? 2 : 1;
     // beyond two shards one LDS add per key ranks it (where the device serves such adds in lane order: checked at nkml_create)
-    const int use_adds = n_shards > ROUTE_BALLOT_SHARDS && c->cfg.device < MAX_DEVICES && g_lds_order[c->cfg.device] > 0;
+    const int use_adds = n_shards > ROUTE_BALLOT_SHARDS && c->lds_ordered;
 #define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, hist)
 #define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, off, \
                                                    (KEY *)d_send_keys, d_send_src)

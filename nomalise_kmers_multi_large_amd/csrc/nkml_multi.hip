@@ -108,6 +108,7 @@ struct nkml_multi {
     int32_t *h_high = nullptr, *h_total = nullptr;
     uint32_t pending_reads = 0;
     bool pending = false, staged_pending = false;
+    bool broken = false; // a batch failed after some shard had counted its part: unusable until nkml_multi_reset
     char err[640];
 };
 
@@ -474,7 +475,9 @@ int nkml_multi_reset(nkml_multi *m)
 {
     if (!m) return NKML_E_ARG;
     m->pending = m->staged_pending = false;
-    return for_each_shard(m, [m](uint32_t i) { return nkml_reset(m->sh[i].ctx); });
+    const int rc = for_each_shard(m, [m](uint32_t i) { return nkml_reset(m->sh[i].ctx); });
+    if (rc == NKML_OK) m->broken = false;
+    return rc;
 }
 
 int nkml_multi_host_staging(nkml_multi *m, uint8_t **seq, uint64_t **offsets)
@@ -502,12 +505,14 @@ int nkml_multi_wait_staged(nkml_multi *m)
 int nkml_multi_submit(nkml_multi *m, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads)
 {
     if (!m) return NKML_E_ARG;
+    if (m->broken) return mfail(m, NKML_E_STATE, "an earlier batch failed half-way and left some shards' tables updated: nkml_multi_reset before counting again");
     if (m->pending) return mfail(m, NKML_E_STATE, "previous batch not collected");
     m->pending_reads = n_reads;
     if (n_reads == 0) { m->pending = true; return NKML_OK; }
     int rc = stage_host_batch(m, seq, offsets, n_reads);
     if (rc != NKML_OK) return rc;
-    if ((rc = run_batch(m, false)) != NKML_OK) return rc;
+    // once the shards have started counting, a failure on one of them leaves the others' tables ahead of it
+    if ((rc = run_batch(m, false)) != NKML_OK) { m->broken = true; return rc; }
     m->pending = true;
     return NKML_OK;
 }
@@ -519,9 +524,9 @@ int nkml_multi_collect(nkml_multi *m, int32_t *high, int32_t *total)
     m->pending = false;
     if (m->pending_reads == 0) return NKML_OK;
     int rc = sync_all(m);
-    if (rc != NKML_OK) return rc;
+    if (rc != NKML_OK) { m->broken = true; return rc; }
     // the contexts' own end-of-batch checks (e.g. the bad-base tally of a device whose route stage did not wait for it)
-    if ((rc = for_each_shard(m, [m](uint32_t i) { return nkml_synchronize(m->sh[i].ctx); })) != NKML_OK) return rc;
+    if ((rc = for_each_shard(m, [m](uint32_t i) { return nkml_synchronize(m->sh[i].ctx); })) != NKML_OK) { m->broken = true; return rc; }
     memcpy(high, m->h_high, (uint64_t)m->pending_reads * sizeof(int32_t));
     memcpy(total, m->h_total, (uint64_t)m->pending_reads * sizeof(int32_t));
     return NKML_OK;
@@ -530,11 +535,12 @@ int nkml_multi_collect(nkml_multi *m, int32_t *high, int32_t *total)
 int nkml_multi_seed(nkml_multi *m, const uint8_t *seq, const uint64_t *offsets, uint32_t n_reads)
 {
     if (!m) return NKML_E_ARG;
+    if (m->broken) return mfail(m, NKML_E_STATE, "an earlier batch failed half-way: nkml_multi_reset before seeding again");
     if (m->pending) return mfail(m, NKML_E_STATE, "previous batch not collected");
     if (n_reads == 0) return NKML_OK;
     int rc = stage_host_batch(m, seq, offsets, n_reads);
     if (rc != NKML_OK) return rc;
-    if ((rc = run_batch(m, true)) != NKML_OK) return rc;
+    if ((rc = run_batch(m, true)) != NKML_OK) { m->broken = true; return rc; }
     return sync_all(m);
 }
 

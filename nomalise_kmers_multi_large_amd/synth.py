@@ -67,3 +67,78 @@ def write_fastq(prefix, n, seed=1, transcripts=2000):
                 i += 1
             f1.write(b"".join(b1))
             f2.write(b"".join(b2))
+
+
+# ---- the same kinds of data made on the GPU (torch), for runs whose input would take minutes to make with numpy ----
+# Test and bench plumbing: torch is only the random number generator and the gather here.
+
+def gpu_pair_steps(n_pairs, pairs_per_step, seed=1, transcripts=None, device="cuda"):
+    """The generator of pair_blocks() on the device: same distribution (transcript lengths, lognormal abundances,
+    fragment lengths, 0.5 % substitutions, 0.01 % N), torch's generator instead of numpy's, so the reads differ from
+    pair_blocks' for the same seed.  Yields (seq uint8[2*m*150] device tensor, m) per step, mates interleaved, forward
+    first; all steps come from one transcriptome, so k-mer counts build up across steps as in one file."""
+    import torch
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    T = int(transcripts) if transcripts else max(50, n_pairs // 1000)
+    lens = torch.randint(600, 3000, (T,), generator=g, device=dev)
+    offs = torch.cumsum(lens, 0) - lens
+    G = torch.randint(0, 4, (int(lens.sum().item()),), generator=g, device=dev, dtype=torch.uint8)
+    ab = torch.exp(2.0 * torch.randn(T, generator=g, device=dev, dtype=torch.float64)) * (lens - 300).double()
+    ab = ab / ab.sum()
+    ascii_t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ar = torch.arange(READ_LEN, device=dev)
+    piece = 500000  # pairs made at a time (bounds the temporaries: about 150 B x 30 per pair)
+    for s in range(0, n_pairs, pairs_per_step):
+        m = min(pairs_per_step, n_pairs - s)
+        out = torch.empty((m, 2, READ_LEN), dtype=torch.uint8, device=dev)
+        for p0 in range(0, m, piece):
+            q = min(piece, m - p0)
+            t = torch.multinomial(ab, q, replacement=True, generator=g)
+            lt = lens[t]
+            fl = torch.minimum(torch.randint(200, 500, (q,), generator=g, device=dev), lt)
+            st = offs[t] + (torch.rand(q, generator=g, device=dev, dtype=torch.float64) * (lt - fl + 1).double()).long()
+            r1 = G[st[:, None] + ar[None, :]]
+            r2 = 3 - G[(st + fl - 1)[:, None] - ar[None, :]]
+            both = torch.stack([r1, r2], dim=1)
+            u = torch.rand(both.shape, generator=g, device=dev)
+            shift = torch.randint(1, 4, both.shape, generator=g, device=dev, dtype=torch.uint8)
+            both = torch.where(u < 0.005, (both + shift) % 4, both)
+            chars = ascii_t[both.long()]
+            chars[u > 0.9999] = ord("N")
+            out[p0:p0 + q] = chars
+        yield out.reshape(-1), m
+
+
+class GpuGenomeReads:
+    """Paired reads that cover a random genome evenly (what makes every k-mer of a bucket reach the depth in the same
+    few batches, and a k > 16 table grow to hundreds of millions of k-mers): fragments of 300-399 bases at uniform
+    positions of a `genome_len`-base genome, 0.1 % substitutions, 0.05 % N.  block(i, n) is a pure function of
+    (seed, i), so two runs over the same block numbers see the same stream."""
+
+    def __init__(self, genome_len=50000000, seed=12345, device="cuda"):
+        import torch
+        self.torch = torch
+        self.dev = torch.device(device)
+        self.g = torch.Generator(device=self.dev)
+        self.g.manual_seed(int(seed))
+        self.genome = torch.randint(0, 4, (genome_len,), generator=self.g, device=self.dev, dtype=torch.uint8)
+        self.ascii = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=self.dev)
+        self.ar = torch.arange(READ_LEN, device=self.dev)
+
+    def block(self, i, n):
+        """(seq uint8[n*300]) of block i: n pairs, mates interleaved, forward first."""
+        torch, g, dev = self.torch, self.g, self.dev
+        g.manual_seed(1000 + int(i))
+        pos = torch.randint(0, self.genome.numel() - 400, (n,), generator=g, device=dev)
+        frag = torch.randint(300, 400, (n,), generator=g, device=dev)
+        fwd = self.genome[pos[:, None] + self.ar]
+        rev = 3 - self.genome[(pos + frag - 1)[:, None] - self.ar]
+        both = torch.stack([fwd, rev], dim=1).reshape(2 * n, READ_LEN)
+        r = torch.rand(both.shape, generator=g, device=dev)
+        sub = torch.randint(0, 4, both.shape, generator=g, device=dev, dtype=torch.uint8)
+        both = torch.where(r < 0.001, sub, both)
+        seq = self.ascii[both.long()]
+        seq[r > 0.9995] = ord("N")
+        return seq.reshape(-1)

@@ -940,6 +940,14 @@ def test_multi_device_table_equals_single_stream(nk, oracle_lib, devices, transp
             with pytest.raises(nk.NkmlError) as e:
                 g.process_batch(seq, off)
             assert e.value.code == -4
+            # some shards have counted their part of that batch: the tables are no longer those of a stream prefix, and the
+            # driver says so until it is reset
+            with pytest.raises(nk.NkmlError) as e2:
+                g.process_batch(*nk.KmerNormaliser._concat(reads[:10]))
+            assert e2.value.code == -5
+            g.reset()
+            h, t = g.process_batch(*nk.KmerNormaliser._concat(reads[:10]))
+            assert len(h) == 10 and g.unique_kmers > 0
     finally:
         if old is None:
             os.environ.pop("NKML_TRANSPORT", None)
@@ -987,10 +995,11 @@ def o_unique_after_seeding(oracle_lib, k, depth, canonical, seeds):
 
 
 @pytest.mark.gpu
-def test_a_device_that_fails_the_lds_order_check_gets_no_partitioned_context():
-    """The partitioned paths rank with returning LDS adds; nkml_create checks the device's order once and refuses a
-    partitioned context if it fails, while the atomic path (and routing, which falls back to ballots) still work and agree
-    with the oracle.  NKML_TEST_LDS_DISORDER makes the check fail; a process of its own, as the result is kept per device."""
+def test_a_device_that_fails_the_lds_order_check_counts_on_the_atomic_path():
+    """The partitioned paths rank with returning LDS adds; nkml_create checks the device's order once.  On a device that
+    fails, the default context quietly becomes an atomic-path context (one line on stderr) and agrees with the oracle, at
+    k = 15 and at k = 25; only a context that asks for the partitioned path by flag is refused.  NKML_TEST_LDS_DISORDER
+    makes the check fail; a process of its own, as the result is kept per device."""
     import subprocess
     import sys
     code = r'''
@@ -1000,24 +1009,27 @@ sys.path.insert(0, ".")
 import nomalise_kmers_multi_large_amd as nk
 from nomalise_kmers_multi_large_amd import binding as B, synth
 from tests.helpers import Oracle
-try:
-    nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=4096, max_batch_bases=4096 * 150)
-    print("CREATED")
-except Exception as e:
-    print("REFUSED", "lane order" in str(e))
 c1, c2 = next(synth.pair_blocks(1000, seed=3, transcripts=4, block=1000))
 seq, off = synth.interleave(c1, c2)
-o = Oracle(15, 20, False)
-want_h, want_t = o.batch(seq, off)
-with nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=4096, max_batch_bases=4096 * 150, flags=B.NKML_F_COUNT_ATOMIC) as g:
-    h, t = g.process_batch(seq, off)
-    print("ATOMIC", bool(np.array_equal(h, want_h) and np.array_equal(t, want_t)))
+for k, canonical in ((15, False), (25, True)):
+    o = Oracle(k, 20, canonical)
+    want_h, want_t = o.batch(seq, off)
+    with nk.KmerNormaliser(k, 20, 0.9, canonical, max_batch_reads=4096, max_batch_bases=4096 * 150) as g:
+        h, t = g.process_batch(seq, off)
+        print("DEFAULT", k, bool(np.array_equal(h, want_h) and np.array_equal(t, want_t)), "partitioned=%d" % g.stats()["partitioned"])
+try:
+    nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=4096, max_batch_bases=4096 * 150, flags=B.NKML_F_COUNT_PARTITIONED)
+    print("FORCED CREATED")
+except Exception as e:
+    print("FORCED REFUSED", "lane order" in str(e))
 '''
     env = dict(os.environ, NKML_TEST_LDS_DISORDER="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert "REFUSED True" in out.stdout, out.stdout + out.stderr
-    assert "ATOMIC True" in out.stdout, out.stdout + out.stderr
+    assert "DEFAULT 15 True partitioned=0" in out.stdout, out.stdout + out.stderr
+    assert "DEFAULT 25 True partitioned=0" in out.stdout, out.stdout + out.stderr
+    assert "FORCED REFUSED True" in out.stdout, out.stdout + out.stderr
+    assert "counting on the atomic path" in out.stderr, out.stderr
 
 
 # ---- routing on its own: the whole output against a stable partition computed with numpy ----

@@ -62,4 +62,29 @@ def test_route_keys_static_rejects_oversize():
         n_keys = ((1 << 19) + 1) * 1024
         with pytest.raises(nk.NkmlError) as e:
             g.route_keys_static(dummy.data_ptr(), n_keys, 1, dummy.data_ptr(), dummy.data_ptr())
-        assert e.value.code == -1 and "scratch" in str(e.value)
+        from nomalise_kmers_multi_large_amd import binding as B
+        assert e.value.code == B.NKML_E_ARG and "scratch" in str(e.value)
+
+
+def test_route_keys_static_allocates_no_device_memory():
+    """The property the entry point is named for: on a fresh context (no routing buffers yet) a call leaves the device's
+    free memory exactly where it was, while the allocating entry point, called next with the same input, takes some."""
+    import torch
+    import nomalise_kmers_multi_large_amd as nk
+    rng = np.random.default_rng(11)
+    n, n_shards = 1 << 26, 4   # 65536 tiles x 4 shards: the allocating variant needs a few MiB of scratch for this
+    with nk.KmerNormaliser(15, 10, 0.9, False, device=0, max_batch_reads=1024, max_batch_bases=1 << 20) as g:
+        keys_t = torch.from_numpy(rng.integers(0, (1 << 30) - 1, n, dtype=np.int64).astype(np.int32)).cuda()
+        send_keys = torch.empty(n, dtype=torch.int32, device="cuda")
+        send_src = torch.empty(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        c_static = g.route_keys_static(keys_t.data_ptr(), n, n_shards, send_keys.data_ptr(), send_src.data_ptr())
+        g.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free1 == free0, "nkml_route_keys_static changed the device's free memory by %d bytes" % (free0 - free1)
+        c_alloc = g.route_keys_device(keys_t.data_ptr(), n, n_shards, send_keys.data_ptr(), send_src.data_ptr())
+        g.synchronize()
+        free2 = torch.cuda.mem_get_info()[0]
+        assert c_alloc == c_static
+        assert free2 < free1, "the probe saw no allocation by nkml_route_keys_device either: it proves nothing"

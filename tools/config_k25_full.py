@@ -13,27 +13,9 @@ PAIRS = int(sys.argv[1]) if len(sys.argv) > 1 else 100000000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 BLOCK = 2000000
 dev = torch.device("cuda", 0)
-g = torch.Generator(device=dev)
-g.manual_seed(12345)
-GENOME = torch.randint(0, 4, (50000000,), generator=g, device=dev, dtype=torch.uint8)
-ASCII = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-ar = torch.arange(150, device=dev)
-
-
-def block(i, n):
-    """Block i of the stream: (seq uint8[n*300], n pairs), mates interleaved, forward first."""
-    g.manual_seed(1000 + i)
-    pos = torch.randint(0, GENOME.numel() - 400, (n,), generator=g, device=dev)
-    frag = torch.randint(300, 400, (n,), generator=g, device=dev)
-    fwd = GENOME[pos[:, None] + ar]
-    rev = 3 - GENOME[(pos + frag - 1)[:, None] - ar]
-    both = torch.stack([fwd, rev], dim=1).reshape(2 * n, 150)
-    r = torch.rand(both.shape, generator=g, device=dev)
-    sub = torch.randint(0, 4, both.shape, generator=g, device=dev, dtype=torch.uint8)
-    both = torch.where(r < 0.001, sub, both)
-    seq = ASCII[both.long()]
-    seq[r > 0.9995] = ord("N")
-    return seq.reshape(-1)
+from nomalise_kmers_multi_large_amd.synth import GpuGenomeReads
+READS = GpuGenomeReads(device=dev)
+block = READS.block
 
 
 def run(batch_pairs):
