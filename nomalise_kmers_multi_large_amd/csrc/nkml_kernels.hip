@@ -64,6 +64,7 @@ struct alignas(256) Counters {
     unsigned long long total_cross; // crossing k-mers since reset
     unsigned int bad_bases;       // bytes outside ACGTN seen by the packer
     unsigned int probe_overflow;  // hashed table: a probe sequence wrapped (table full) - must stay 0
+    unsigned int hp_left;         // hashed table, partitioned: buckets of the batch that the fast bucket kernel left to the general one
 };
 
 struct Slot {
@@ -1559,15 +1560,19 @@ int alloc_table(nkml_ctx *c)
             c->hp_log2_local_max = HP_DEFAULT_LOG2_LOCAL;
             if (const char *e = getenv("NKML_HP_LOG2_LOCAL")) { // tuning aid
                 const int v = atoi(e);
-                if (v >= 2 && v <= HB_MAX_SLOTS_LOG2) c->hp_log2_local_max = v; // at least one set of slots
+                if (v >= 3 && v <= HB_MAX_SLOTS_LOG2) c->hp_log2_local_max = v; // at least one set of slots
             }
             if (const char *e = getenv("NKML_HP_LOG2_BUCKET")) { // test aid: a tiny table, so that small inputs make it grow
                 const int v = atoi(e);
-                if (v >= 2 && v <= HP_MAX_LOG2_BUCKET) { c->hp_log2_bucket = v; c->capacity = 65536ull << v; } // at least one set of slots
+                if (v >= 3 && v <= HP_MAX_LOG2_BUCKET) { c->hp_log2_bucket = v; c->capacity = 65536ull << v; } // at least one set of slots
             }
             HIPCHK(c, hipMalloc(&c->hp_table, c->capacity * sizeof(unsigned long long)));
             HIPCHK(c, hipMalloc(&c->hp_done, HP_MAX_GRID * sizeof(uint32_t)));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_count_bucket), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(HB_MAX_SLOTS * 12)));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_count_bucket_fast<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(HB_MAX_SLOTS * 12)));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_count_bucket_fast<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(HB_MAX_SLOTS * 12)));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HB_MAX_SLOTS * 8)));
         } else {
@@ -1595,7 +1600,7 @@ int alloc_table(nkml_ctx *c)
         HIPCHK(c, hipMalloc(&c->pt_scanB, 256 * (c->pt_tiles_b + 1) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_pad, 260 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_startB, 260 * sizeof(uint32_t)));
-        if (!c->hashpart) HIPCHK(c, hipMalloc(&c->pt_bounds, ((c->capacity >> PT_LOWBITS) + 2) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->pt_bounds, ((c->hashpart ? (uint64_t)65536 : (c->capacity >> PT_LOWBITS)) + 2) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_tally, (c->hashpart ? (uint64_t)HP_MAX_GRID : (c->capacity >> PT_LOWBITS) + 1) * sizeof(uint4)));
         HIPCHK(c, hipMalloc(&c->pt_totals, 256 * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc(&c->pt_chunks, 256 * ((c->pt_tiles_b + 1 + PT_CH - 1) / PT_CH + 1) * sizeof(uint32_t)));
@@ -2243,20 +2248,37 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
         const HpGeom g0 = hp_geom(c, c->hp_log2_bucket);
         HIPCHK(c, hipMemsetAsync(c->hp_done, 0, ((uint64_t)65536 << (g0.log2_bucket - g0.log2_local)) * sizeof(uint32_t), c->stream));
     }
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->hp_left, 0, sizeof(unsigned int), c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_pt_bucket_bounds, 65536u / 256 + 1, 256, 0, c->stream, c->pt_scanB, c->pt_pad, 65536u, c->pt_bounds);
     uint32_t n_ranges = 0;
+    const bool general_only = getenv("NKML_HP_GENERAL_KERNEL") != nullptr; // tuning / test aid: every bucket through the general kernel
     for (int attempt = 0;; attempt++) {
         const HpGeom geo = hp_geom(c, c->hp_log2_bucket);
         n_ranges = 65536u << (geo.log2_bucket - geo.log2_local);
         const size_t lds = ((size_t)12) << geo.log2_local;
         // the first pass's output is free by now: the workgroups regroup their buckets' keys into it
-        hipLaunchKernelGGL(k_hp_count_bucket, 65536u, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_scanB, c->pt_pad, c->hp_table, geo,
-                           (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr, c->hp_keysA);
-        HIPCHK(c, hipGetLastError());
+        if (!general_only) {
+            if (geo.log2_bucket > geo.log2_local)
+                hipLaunchKernelGGL(k_hp_count_bucket_fast<true>, 65536u, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_bounds, c->hp_table, geo, (uint32_t)c->cfg.depth,
+                                   seeding ? 1 : 0, attempt == 0 ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr, c->hp_keysA);
+            else
+                hipLaunchKernelGGL(k_hp_count_bucket_fast<false>, 65536u, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_bounds, c->hp_table, geo, (uint32_t)c->cfg.depth,
+                                   seeding ? 1 : 0, attempt == 0 ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr, c->hp_keysA);
+            HIPCHK(c, hipGetLastError());
+        }
         // from here on part of the batch is in the table: a failure leaves the context unusable until nkml_reset
         c->broken = true;
         if (profile && attempt == 0) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        if ((rc = fetch_counters(c)) != NKML_OK) return rc; // did every bucket fit?
+        if ((rc = fetch_counters(c)) != NKML_OK) return rc; // did every bucket fit?  did the fast kernel leave any?
+        if (general_only || c->h_ctr->hp_left) {
+            // buckets with more keys than 16-bit counters hold (a k-mer repeated throughout the batch): the general kernel
+            // takes every sub-range that is not marked done
+            hipLaunchKernelGGL(k_hp_count_bucket, 65536u, HB_THREADS, lds, c->stream, c->hp_keysB, c->pt_scanB, c->pt_pad, c->hp_table, geo,
+                               (uint32_t)c->cfg.depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally, c->hp_done, c->d_ctr, c->hp_keysA);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = fetch_counters(c)) != NKML_OK) return rc;
+        }
         if (!c->h_ctr->probe_overflow) break;
         if (attempt >= HP_MAX_LOG2_BUCKET) return fail(c, NKML_E_STATE, "hashed table overflow (capacity %llu)", (unsigned long long)c->capacity);
         HIPCHK(c, hipMemsetAsync(&c->d_ctr->probe_overflow, 0, sizeof(unsigned int), c->stream));

@@ -60,9 +60,9 @@ for case in range(cases):
         for var in ("NKML_HP_LOG2_BUCKET", "NKML_HP_LOG2_LOCAL", "NKML_HP_LEAVE_SLOTS"):
             os.environ.pop(var, None)
         if k > 16 and flags == binding.NKML_F_COUNT_PARTITIONED:
-            os.environ["NKML_HP_LOG2_BUCKET"] = str(int(rng.choice([2, 3, 4, 6])))
+            os.environ["NKML_HP_LOG2_BUCKET"] = str(int(rng.choice([3, 4, 5, 6])))
             if rng.random() < 0.7:
-                os.environ["NKML_HP_LOG2_LOCAL"] = str(int(rng.choice([2, 3, 4, 5])))
+                os.environ["NKML_HP_LOG2_LOCAL"] = str(int(rng.choice([3, 4, 5, 6])))
             if rng.random() < 0.3:
                 os.environ["NKML_HP_LEAVE_SLOTS"] = str(65536 << int(rng.choice([3, 4, 5])))
         g = KmerNormaliser(k, depth, 0.9, canonical, max_batch_reads=1024, max_batch_bases=1 << 19, flags=flags,

@@ -115,11 +115,11 @@ def test_random_reads_small_keyspace(nk, oracle_lib, k, depth, canonical, chunk)
 @pytest.mark.parametrize("k,depth,canonical,log2_bucket,per_batch", [
     (17, 3, False, None, 700), (21, 2, True, None, 512), (25, 4, True, None, 2000), (31, 3, False, None, 300), (31, 50, True, None, 700),
     (25, 100, True, None, 2000), (21, 200, False, None, 2000),
-    (25, 4, True, 2, 2000),    # four slots per bucket to begin with: the table doubles between batches and inside a batch
-    (31, 3, False, 3, 150), (19, 5, True, 2, 5000),
-    # a workgroup's LDS table of 4 (8, 16) slots: buckets of several sub-ranges, their keys regrouped by sub-range first
-    # (2-8 sub-ranges: ballots; more: LDS counters), one bucket with more keys than the regrouping's 16-bit index holds
-    (25, 4, True, (2, 2), 2000), (31, 3, False, (2, 3), 5000), (21, 100, True, (3, 2), 5000), (23, 2, False, (2, 4), 300),
+    (25, 4, True, 3, 2000),    # eight slots (one set) per bucket to begin with: the table doubles between batches and inside a batch
+    (31, 3, False, 3, 150), (19, 5, True, 3, 5000),
+    # a workgroup's LDS table of 8 (16, 32) slots: buckets of several sub-ranges, their keys regrouped by sub-range first
+    # (2-8 sub-ranges: ballots; more: LDS counters), one bucket with more keys than 16-bit counters hold (the general kernel's)
+    (25, 4, True, (3, 3), 2000), (31, 3, False, (3, 4), 5000), (21, 100, True, (3, 3), 5000), (23, 2, False, (3, 5), 300),
 ])
 @pytest.mark.parametrize("on", [True, False])
 def test_hashed_table_both_counting_paths(nk, oracle_lib, k, depth, canonical, log2_bucket, per_batch, on):
@@ -187,15 +187,15 @@ def test_hashed_table_moves_from_the_partitioned_to_the_atomic_path(nk, oracle_l
     o = oracle_lib(k, depth, True)
     want = [o.read(r) for r in reads]
     saved = {v: os.environ.get(v) for v in ("NKML_HP_LOG2_BUCKET", "NKML_HP_LEAVE_SLOTS", "NKML_PARTITIONED")}
-    os.environ["NKML_HP_LOG2_BUCKET"] = "2"
-    os.environ["NKML_HP_LEAVE_SLOTS"] = str(65536 << 2)
+    os.environ["NKML_HP_LOG2_BUCKET"] = "3"
+    os.environ["NKML_HP_LEAVE_SLOTS"] = str(65536 << 3)
     os.environ.pop("NKML_PARTITIONED", None)
     try:
         with nk.KmerNormaliser(k, depth, 0.9, True, max_batch_reads=400, max_batch_bases=400 * 200) as g:
-            assert g.stats()["partitioned"] == 1 and g.stats()["capacity"] == 65536 << 2
+            assert g.stats()["partitioned"] == 1 and g.stats()["capacity"] == 65536 << 3
             ok, high, total = g.process_sequence_single(reads)
             st = g.stats()
-            assert st["partitioned"] == 0 and st["capacity"] > 65536 << 2
+            assert st["partitioned"] == 0 and st["capacity"] > 65536 << 3
             np.testing.assert_array_equal(high, [w[1] for w in want])
             np.testing.assert_array_equal(total, [w[2] for w in want])
             assert g.unique_kmers == o.unique
