@@ -1349,7 +1349,7 @@ __global__ void __launch_bounds__(LOC_WAVES * 64) k_lds_order_check(uint32_t *ba
     __shared__ uint32_t other[LOC_WAVES][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t nbad = 0, sink = 0;
-    for (uint32_t spread = 1; spread <= 256; spread <<= 1) {
+    for (uint32_t spread = 1; spread <= 256; spread <<= 2) { // 1, 4, 16, 64, 256 counters per wavefront
 #pragma unroll
         for (int j = 0; j < 4; j++) { wcnt[wv][j * 64 + lane] = 0; other[wv][j * 64 + lane] = lane; }
         wave_lds_handover();
@@ -2131,9 +2131,9 @@ __global__ void __launch_bounds__(256) k_hp_to_slots(const unsigned long long *_
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += stride) {
         const unsigned long long v = table[i];
         if (!v) continue;
-        const unsigned long long hash = ((i >> log2_bucket) << 48) | (v & HP_KEYMASK), code = unmix64(hash);
+        const unsigned long long code = hp_unhash(((i >> log2_bucket) << 48) | (v & HP_KEYMASK));
         const uint32_t cnt = (uint32_t)(v >> HP_COUNT_SHIFT) & HP_CMAX;
-        uint64_t h = hash & cap_mask, probes = 0; // find_or_insert starts from mix64(code) = hash
+        uint64_t h = mix64(code) & cap_mask, probes = 0; // where find_or_insert starts
         for (; probes <= cap_mask; probes++) {
             if (atomicCAS(&slots[h].key, 0ull, code) == 0ull) {
                 slots[h].count = cnt;
@@ -2505,7 +2505,7 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
             uint32_t bad = 0;
             CREATE_HIP(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
             const uint32_t cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
-            hipLaunchKernelGGL(k_lds_order_check, cus * 4u * 2u, LOC_WAVES * 64, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
+            hipLaunchKernelGGL(k_lds_order_check, cus * 4u, LOC_WAVES * 64, 0, c->stream, reinterpret_cast<uint32_t *>(c->d_ctr));
             CREATE_HIP(hipGetLastError());
             CREATE_HIP(hipMemcpyAsync(&bad, c->d_ctr, sizeof bad, hipMemcpyDeviceToHost, c->stream));
             CREATE_HIP(hipStreamSynchronize(c->stream));
