@@ -52,21 +52,14 @@ def algorithmic_bytes_per_pair(k):
     return 2 * READ_LEN + 2 * w * 32 + 16
 
 
-def make_dataset(n_pairs, seed, pairs_per_step, first_pair=0):
-    """List of per-step (seq uint8[...], offsets int64[...]) host arrays."""
-    steps, buf1, buf2, have = [], [], [], 0
-    transcripts = max(50, n_pairs // 1000)
-    for c1, c2 in synth.pair_blocks(n_pairs, seed=seed, transcripts=transcripts, block=100000):
-        buf1.append(c1)
-        buf2.append(c2)
-        have += c1.shape[0]
-        while have >= pairs_per_step:
-            a1, a2 = np.concatenate(buf1), np.concatenate(buf2)
-            steps.append(synth.interleave(a1[:pairs_per_step], a2[:pairs_per_step]))
-            buf1, buf2 = [a1[pairs_per_step:]], [a2[pairs_per_step:]]
-            have -= pairs_per_step
-    if have:
-        steps.append(synth.interleave(np.concatenate(buf1), np.concatenate(buf2)))
+def make_dataset(n_pairs, seed, pairs_per_step, dev):
+    """Per-step (seq uint8 tensor, offsets int64 tensor, n_reads, n_bases) on the device.  The reads are made there too
+    (synth.gpu_pair_steps: the generator of synth.pair_blocks with torch's random numbers - same transcript, abundance,
+    fragment and error model; 40 M pairs with numpy took minutes of host time per run)."""
+    steps = []
+    for seq, m in synth.gpu_pair_steps(n_pairs, pairs_per_step, seed=seed, transcripts=max(50, n_pairs // 1000), device=dev):
+        off = torch.arange(0, 2 * m + 1, dtype=torch.int64, device=dev) * READ_LEN
+        steps.append((seq, off, 2 * m, int(seq.numel())))
     return steps
 
 
@@ -259,10 +252,7 @@ def main():
 
     # every rank generates its own slice of the stream (different seed per rank: different reads of the same
     # transcript mix would need a shared transcriptome; a per-rank dataset keeps the per-GPU work identical)
-    host_steps = make_dataset(data_steps * pps, args.seed + 1000 * rank, pps)
-    dev_steps = []
-    for seq, off in host_steps:
-        dev_steps.append((torch.from_numpy(seq).to(dev), torch.from_numpy(off.astype(np.int64)).to(dev), len(off) - 1, len(seq)))
+    dev_steps = make_dataset(data_steps * pps, args.seed + 1000 * rank, pps, dev)
 
     if world == 1:
         from nomalise_kmers_multi_large_amd.normaliser import KmerNormaliser
@@ -290,7 +280,7 @@ def main():
             """(normaliser, engine, mode) or the exception; a rank must not go on alone, so the outcome is agreed on"""
             try:
                 made = make_multi_gpu_normaliser(k, depth, cov, canonical, local_rank, max_reads=2 * pps, max_bases=2 * pps * READ_LEN,
-                                                 profile=True, stage_through_host=rehearse, root_only=True, mode=mode)
+                                                 profile=True, stage_through_host=rehearse, root_only=True, mode=mode, time_phases=True)
             except Exception as e:  # e.g. a context that does not fit: every rank falls back together
                 made = e
             ok = torch.tensor([0 if isinstance(made, Exception) else 1], dtype=torch.int64, device="cpu" if rehearse else dev)
@@ -326,28 +316,44 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warmup: the first steps of the stream, then forget the counts so the timed region starts from an empty table
+    def timed(n_steps):
+        """n_steps steps from an empty table; returns the elapsed time (maximum over the ranks) in seconds."""
+        eng.reset()
+        sync()
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(i, i + 1 == n_steps)
+        sync()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # warmup: the first steps of the stream (timed() then forgets the counts so the timed region starts from an empty table)
     for i in range(args.warmup):
         step(i, i + 1 == args.warmup)
     sync()
-    eng.reset()
-    sync()
 
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, i + 1 == args.steps)
-    sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The 10 M-read configuration itself is 5 steps of 2 M pairs from an empty table.  A longer run (the table fills up,
+    # more k-mers are saturated, later steps are a little cheaper) reports it beside the all-steps value.
+    config2 = None
+    if world == 1 and args.steps != 5 and pps == 2000000 and len(dev_steps) >= 5:
+        dt5 = timed(5)
+        st5 = eng.stats()
+        stage5 = st5["count_stage_ms"] / max(1, st5["count_kernel_launches"]) if st5.get("partitioned") else st5["count_kernel_ms"] / max(1, st5["count_kernel_launches"])
+        occ5 = st5["kmers_counted"] / max(1, st5["count_kernel_launches"])
+        config2 = {"workload": "the first 5 steps: 10 M pairs from an empty table", "steps": 5, "ms_per_step": dt5 * 1e3 / 5, "value": 5 * pps / dt5,
+                   "counting_stage_ms": stage5, "roofline_frac": 32.0 * occ5 / (stage5 * 1e-3) / 1e9 / HBM_PEAK_GBS if stage5 > 0 else None}
+
+    elapsed = timed(args.steps)
     # decisions of the last pass over the data (all of them when the run is no longer than the dataset)
     kept_pairs = int(d_keep_all.sum(dtype=torch.int64).item()) if d_keep_all is not None else None
     cdev = "cpu" if rehearse else dev
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
 
     st = eng.stats()
     total_pairs = n_pairs * world
@@ -357,6 +363,36 @@ def main():
         u = torch.tensor([unique], dtype=torch.int64, device=cdev)
         dist.all_reduce(u)
         unique = int(u.item())
+
+    multi = None
+    if dist is not None:
+        # where a step's time goes on every rank (HIP events on the launch stream, host clock for the host round trips)
+        rep = eng.phase_report()
+        rep["rank"] = rank
+        rep["rccl_world_size"] = dist.get_world_size()
+        rep["device"] = torch.cuda.get_device_name(dev)
+        reports = [None] * world
+        dist.all_gather_object(reports, rep)
+        if rank == 0:
+            names = sorted({n for r in reports for n in r["ms_per_step"]})
+            bnames = sorted({n for r in reports for n in r["bytes_per_step"]})
+
+            def spread(vals):
+                v = sorted(vals)
+                return {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+            ms_step = elapsed * 1e3 / args.steps
+            multi = {"mode": multi_mode, "world_size": world, "backend": "gloo (rehearsal)" if rehearse else "nccl (RCCL)",
+                     "phase_ms_per_step": {n: spread([r["ms_per_step"].get(n, 0.0) for r in reports]) for n in names},
+                     "bytes_per_step_per_rank": {n: spread([r["bytes_per_step"].get(n, 0.0) for r in reports]) for n in bnames},
+                     "note": "device phases are HIP-event times on the launch stream of each rank; an exchange phase is the part of the "
+                             "collective that no other work covered; min / median / max over the ranks"}
+            for n in bnames:   # achieved rate per rank if the traffic had the whole step to travel, and within its own phase
+                if "sent" in n or "received" in n:
+                    multi.setdefault("GBps_per_rank_over_the_step", {})[n] = spread([r["bytes_per_step"].get(n, 0.0) / (ms_step * 1e-3) / 1e9 for r in reports])
+            kx = [r["ms_per_step"].get("key exchange (not hidden)") for r in reports]
+            kb = [r["bytes_per_step"].get("keys sent to other ranks") for r in reports]
+            if all(v for v in kx) and all(v for v in kb):
+                multi["key_exchange_GBps_per_rank_in_its_exposed_time"] = spread([b / (t * 1e-3) / 1e9 for b, t in zip(kb, kx)])
 
     if rank == 0:
         launches = max(1, st["count_kernel_launches"])
@@ -417,7 +453,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32" if k <= 16 else "u64",
-            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
+            "data": "synthetic (made on the GPU: synth.gpu_pair_steps)" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
             "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d%s depth=%d coverage=%g, %s" % (
                 n_pairs, k, " --canonical" if canonical else "", depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
                     world, "packed reads all-gathered, every GPU counts its shard" if multi_mode == "replicated" else "RCCL all-to-all of k-mers")),
@@ -429,6 +465,8 @@ def main():
             "algorithmic_GBps_whole_path": value * algorithmic_bytes_per_pair(k) / 1e9,
             "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "traffic_source": ("profiles/pmc_counting_stage.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this command "
+                                                 "(a separate run: PMC passes cannot share a run with the timing)") if traffic else None,
                               "algorithmic_bytes_per_launch": alg_bytes_per_launch}, **aux),
             "table": {"table_bytes": st["table_bytes"], "slots": st["capacity"], "resizes": st["resizes"],
                       "saturated_fraction": st["kmers_saturated"] / max(1, occ), "crossing_kmers": st["crossing_kmers"],
@@ -437,7 +475,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sample_pairs = min(args.cpu_sample_pairs, pps)
             sample_pairs -= sample_pairs % 100000 if sample_pairs >= 100000 else 0
-            seq0, off0 = host_steps[0]
+            seq0 = dev_steps[0][0].cpu().numpy()
+            off0 = dev_steps[0][1].cpu().numpy().astype(np.uint64)
             sseq = seq0[: sample_pairs * 2 * READ_LEN]
             soff = off0[: sample_pairs * 2 + 1]
             # decisions of the GPU run on the same prefix (step 0 starts from the empty table, as the CPU run does)
@@ -453,6 +492,13 @@ def main():
         elif world == 1:
             result["cpu_baseline"] = None
         result["kept_pairs"] = kept_pairs
+        if config2 is not None:
+            result["config2"] = config2
+        elif world == 1 and args.steps == 5 and pps == 2000000:
+            result["config2"] = {"workload": "this run (5 steps of 2 M pairs from an empty table)", "steps": 5, "ms_per_step": result["ms_per_step"],
+                                 "value": value, "counting_stage_ms": unit_ms if partitioned else None, "roofline_frac": result["roofline"]["frac"]}
+        if multi is not None:
+            result["multi_gpu"] = multi
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import binding as B
+from .phases import Phases
 
 GAP_READS = 1024     # a region's unused tail is cut into at most this many filler reads ...
 GAP_BASES = 4096     # ... of at least this many bases (one lane walks one read in the per-read reduction)
@@ -119,8 +120,9 @@ class HipReplicaEngine:
 class ReplicatedReadsNormaliser:
     """Same face as ShardedNormaliser: one step = every rank's batch, processed as one global batch in rank-major order."""
 
-    def __init__(self, engine, group=None, stage_through_host=False, check_words=None, root_only=False):
+    def __init__(self, engine, group=None, stage_through_host=False, check_words=None, root_only=False, time_phases=False):
         self.eng = engine
+        self.phases = Phases(time_phases, getattr(engine, "dev", None))
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -202,15 +204,18 @@ class ReplicatedReadsNormaliser:
         eng, W = self.eng, self.world
         cdev = "cpu" if self.stage_through_host or not seq.is_cuda else seq.device
         longest = int((offsets[1: n_reads + 1] - offsets[:n_reads]).max()) if n_reads else 0
-        meta = torch.empty(3 * W, dtype=torch.int64, device=cdev)
-        self._gather_equal(meta, torch.tensor([n_reads, n_bases, longest], dtype=torch.int64, device=cdev))
-        meta = meta.tolist()
+        with self.phases.host("sizes (host round trip)"):
+            meta = torch.empty(3 * W, dtype=torch.int64, device=cdev)
+            self._gather_equal(meta, torch.tensor([n_reads, n_bases, longest], dtype=torch.int64, device=cdev))
+            meta = meta.tolist()
         x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases), "reads": meta[0::3], "bases": meta[1::3],
              "narrow": max(meta[2::3]) < 65536}
         x["region"], x["fillers"], x["first"], x["total_reads"] = step_layout(x["reads"], x["bases"])
         self._buffer ^= 1
         x["words_all"] = eng.gather_buffer(W * x["region"], self._buffer)
-        mine_words = eng.pack(seq, n_bases, x["region"], self._buffer)
+        with self.phases.dev("pack"):
+            mine_words = eng.pack(seq, n_bases, x["region"], self._buffer)
+        self.phases.add_bytes("packed reads received from other ranks", 4 * x["region"] * (W - 1))
         # read offsets travel as 32-bit numbers local to the rank's region
         x["slot"] = max(x["reads"]) + 1
         mine = torch.zeros(x["slot"], dtype=torch.int32, device=seq.device)
@@ -234,20 +239,27 @@ class ReplicatedReadsNormaliser:
             raise RuntimeError("process_step was announced another batch by the previous call's `then`")
         if x is None:
             x = self._start_exchange(seq, offsets, n_reads, n_bases)
-        for w in x["works"]:
-            if w is not None:
-                w.wait()
+        ph = self.phases
+        with ph.dev("all-gather of packed reads (not hidden)"):
+            for w in x["works"]:
+                if w is not None:
+                    w.wait()
         slot = x["slot"]
         goff = global_offsets([x["off_all"][r * slot:(r + 1) * slot] for r in range(W)], x["reads"], x["bases"], x["region"], x["fillers"])
         if then is not None:
             self._ahead = self._start_exchange(*then)
         err = None
         try:
-            counters = eng.process_packed(x["words_all"], goff, x["total_reads"], W * x["region"] * 16)
+            with ph.dev("count (own shard of every rank's reads)"):
+                counters = eng.process_packed(x["words_all"], goff, x["total_reads"], W * x["region"] * 16)
         except Exception as e:   # e.g. a byte outside ACGTN among this rank's reads: only this rank's context knows
             err = e
-        self._agree(err, seq)
-        self._sum_counters(counters, x["narrow"])
+        with ph.host("agree (host round trip)"):
+            self._agree(err, seq)
+        with ph.dev("sum of per-read counters"):
+            self._sum_counters(counters, x["narrow"])
+        ph.add_bytes("per-read counters sent", (4 if x["narrow"] else 8) * x["total_reads"])
+        ph.step_done()
         if self.root_only and self.rank != 0:
             return None, None, None
         per_rank = [counters[:, x["first"][r]: x["first"][r] + x["reads"][r]] for r in range(W)]
@@ -259,13 +271,17 @@ class ReplicatedReadsNormaliser:
 
     def reset(self):
         self.eng.reset()
+        self.phases.reset()
+
+    def phase_report(self):
+        return self.phases.report()
 
     def stats(self):
         return self.eng.stats()
 
 
 def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False,
-                              stage_through_host=False, mode=None, group=None, root_only=False):
+                              stage_through_host=False, mode=None, group=None, root_only=False, time_phases=False):
     """The multi-GPU normaliser that suits the job: replicated reads on up to four GPUs when a step fits one context
     (measured per-rank compute of a 2 M-pair step at k=15: 10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs, plus one all-gather
     of packed reads, hidden behind the counting, and one sum of counters; the key exchange would put 0.5-1.5 GB per
@@ -278,8 +294,9 @@ def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_rea
     mode = mode or os.environ.get("NKML_MULTI_GPU") or ("replicated" if world <= 4 and fits(ksize, depth, world, max_bases) else "exchange")
     if mode == "replicated":
         engine = HipReplicaEngine(ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=profile)
-        return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host, root_only=root_only), engine, mode
+        return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host, root_only=root_only,
+                                         time_phases=time_phases), engine, mode
     if mode != "exchange":
         raise ValueError("NKML_MULTI_GPU must be 'replicated' or 'exchange', not %r" % mode)
     engine = HipShardEngine(ksize, depth, coverage, canonical, device, max_reads=max_reads, max_bases=max_bases, profile=profile)
-    return ShardedNormaliser(engine, group=group, stage_through_host=stage_through_host), engine, mode
+    return ShardedNormaliser(engine, group=group, stage_through_host=stage_through_host, time_phases=time_phases), engine, mode

@@ -22,6 +22,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .phases import Phases
+
 
 class HipShardEngine:
     """Stage-by-stage face of the HIP library on one GPU, holding torch tensors for the buffers."""
@@ -116,8 +118,10 @@ class HipShardEngine:
 class ShardedNormaliser:
     """One step = every rank's batch of reads, processed as one global batch (rank-major stream order)."""
 
-    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=768 << 20, check_elems=None):
+    def __init__(self, engine, group=None, gather_to_root=True, stage_through_host=False, max_message_bytes=768 << 20, check_elems=None,
+                 time_phases=False):
         self.eng = engine
+        self.phases = Phases(time_phases, getattr(engine, "dev", None))
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -221,21 +225,25 @@ class ShardedNormaliser:
             q.wait()
         return [b.to(packed.device) for b in bufs] if host else bufs
 
-    def _exchange_counts(self, send_counts, like, failed=False, cap=None):
-        """What every peer sends here, the largest segment of the whole exchange (for the round count), and whether the
-        step has to stop: a rank whose routing failed (`failed`: e.g. a read with a byte outside ACGTN) or that would
-        receive more keys than it was sized for (`cap`) must not be left alone with its exception while its peers walk
-        into the next collective, so the outcome travels with the counts and every rank learns it here."""
+    def _exchange_counts(self, send_counts, like, failed=False, cap=None, n_reads=0):
+        """What every peer sends here, the largest segment of the whole exchange (for the round count), every rank's number
+        of reads (for the gather at the end of the step), and whether the step has to stop: a rank whose routing failed
+        (`failed`: e.g. a read with a byte outside ACGTN) or that would receive more keys than it was sized for (`cap`) must
+        not be left alone with its exception while its peers walk into the next collective.  All of it travels in one small
+        all-gather (the whole table of counts: world x world numbers), one host round trip per step; whether a rank would
+        receive too much can be worked out by everybody from that table."""
+        W = self.world
         cdev = "cpu" if self.stage_through_host or not like.is_cuda else like.device
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=cdev)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv = [int(x) for x in rc.tolist()]
-        too_many = cap is not None and sum(recv) > cap
-        agg = torch.stack([sc.max(), torch.tensor(1 if (failed or too_many) else 0, dtype=torch.int64, device=cdev)])
-        dist.all_reduce(agg, op=dist.ReduceOp.MAX, group=self.group)
-        peak, stop = agg.tolist()
-        return recv, int(peak), bool(stop), too_many
+        mine = torch.tensor(list(send_counts) + [1 if failed else 0, int(n_reads), -1 if cap is None else int(cap)], dtype=torch.int64, device=cdev)
+        table = torch.empty(W * (W + 3), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(table, mine, group=self.group)
+        rows = table.view(W, W + 3).tolist()
+        recv = [int(rows[p][self.rank]) for p in range(W)]
+        peak = max(max(r[:W]) for r in rows)
+        over = [rows[q][W + 2] >= 0 and sum(rows[p][q] for p in range(W)) > rows[q][W + 2] for q in range(W)]
+        stop = any(r[W] for r in rows) or any(over)
+        self._n_reads_all = [int(r[W + 1]) for r in rows]
+        return recv, int(peak), bool(stop), bool(over[self.rank])
 
     def _agree(self, err, like):
         """Every rank calls this after a stage that can fail on one rank alone (err = its exception or None): all raise, or none."""
@@ -256,15 +264,18 @@ class ShardedNormaliser:
         x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases)}
         err = None
         try:
-            if hasattr(eng, "kmerise_route"):
-                send_keys, x["send_src"], x["send_counts"], x["n_positions"] = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
-            else:
-                keys = eng.kmerise(seq, offsets, n_reads, n_bases)
-                send_keys, x["send_src"], x["send_counts"] = eng.route(keys, W)
-                x["n_positions"] = keys.numel()
+            with self.phases.dev("route"):
+                if hasattr(eng, "kmerise_route"):
+                    send_keys, x["send_src"], x["send_counts"], x["n_positions"] = eng.kmerise_route(seq, offsets, n_reads, n_bases, W)
+                else:
+                    keys = eng.kmerise(seq, offsets, n_reads, n_bases)
+                    send_keys, x["send_src"], x["send_counts"] = eng.route(keys, W)
+                    x["n_positions"] = keys.numel()
         except Exception as e:   # this rank cannot go on, but its peers have to hear of it before anyone raises
             err, send_keys, x["send_counts"] = e, seq[:0], [0] * W
-        x["recv_counts"], x["peak"], stop, too_many = self._exchange_counts(x["send_counts"], seq, err is not None, getattr(eng, "cap", None))
+        with self.phases.host("sizes (host round trip)"):
+            x["recv_counts"], x["peak"], stop, too_many = self._exchange_counts(x["send_counts"], seq, err is not None, getattr(eng, "cap", None), n_reads)
+        x["n_reads_all"] = self._n_reads_all
         if stop:
             if err is not None:
                 raise err
@@ -277,6 +288,9 @@ class ShardedNormaliser:
         else:
             x["recv_keys"] = eng.recv_buffer(sum(x["recv_counts"]))
             x["owed"] = self._all_to_all_start(x["recv_keys"], send_keys, x["recv_counts"], x["send_counts"], x["peak"])
+            away = sum(x["send_counts"]) - x["send_counts"][self.rank]
+            self.phases.add_bytes("keys sent to other ranks", away * send_keys.element_size())
+            self.phases.add_bytes("keys received from other ranks", (sum(x["recv_counts"]) - x["recv_counts"][self.rank]) * send_keys.element_size())
         x["alive"] = (send_keys, seq, offsets)
         return x
 
@@ -293,35 +307,45 @@ class ShardedNormaliser:
             raise RuntimeError("process_step was announced another batch by the previous call's `then`")
         if x is None:
             x = self._start_exchange(seq, offsets, n_reads, n_bases)
-        self._all_to_all_finish(x["owed"])
+        ph = self.phases
+        with ph.dev("key exchange (not hidden)"):
+            self._all_to_all_finish(x["owed"])
         if then is not None:
             self._ahead = self._start_exchange(*then)
         err = None
         try:
-            recv_flags = eng.count(x["recv_keys"])
+            with ph.dev("count"):
+                recv_flags = eng.count(x["recv_keys"])
         except Exception as e:   # e.g. the table shard cannot grow any further
             err = e
-        self._agree(err, seq)
+        with ph.host("agree (host round trip)"):
+            self._agree(err, seq)
         if W == 1 and hasattr(eng, "kmerise_route"):
             back = recv_flags
         else:
             back = eng.back_buffer(sum(x["send_counts"]))
-            self._all_to_all(back, recv_flags, x["send_counts"], x["recv_counts"], x["peak"])
-        flags = eng.unroute(back, x["send_src"], x["n_positions"])
-        high, total = eng.reduce(flags, offsets, n_reads)
+            with ph.dev("flag exchange"):
+                self._all_to_all(back, recv_flags, x["send_counts"], x["recv_counts"], x["peak"])
+            ph.add_bytes("flags sent to other ranks", sum(x["recv_counts"]) - x["recv_counts"][self.rank])
+        with ph.dev("flags home + per-read sums"):
+            flags = eng.unroute(back, x["send_src"], x["n_positions"])
+            high, total = eng.reduce(flags, offsets, n_reads)
         gathered = None
         if self.gather_to_root:
-            cdev = "cpu" if self.stage_through_host else high.device
-            n_all = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(W)]
-            dist.all_gather(n_all, torch.tensor([n_reads], dtype=torch.int64, device=cdev), group=self.group)
-            gathered = self._p2p_gather(torch.stack([high, total]), [int(v.item()) for v in n_all])
+            with ph.dev("gather to rank 0"):
+                gathered = self._p2p_gather(torch.stack([high, total]), x["n_reads_all"])
+        ph.step_done()
         return high, total, gathered
+
+    def phase_report(self):
+        return self.phases.report()
 
     def synchronize(self):
         self.eng.synchronize()
 
     def reset(self):
         self.eng.reset()
+        self.phases.reset()
 
     def stats(self):
         return self.eng.stats()
