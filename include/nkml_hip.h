@@ -80,6 +80,16 @@ typedef struct nkml_config {
                                   .partitioned tells which path a context is on); atomics otherwise.  The environment
                                   variable NKML_PARTITIONED=0/1 overrides the choice like the flags.  Per-read results are
                                   identical either way; dumped counts of k-mers past the depth differ (see nkml_dump_table). */
+#define NKML_F_VERIFY_RANKS 16u /* check every batch of the partitioned paths with kernels that do not rely on the order in
+                                  which the LDS serves the returning adds of one instruction (the partitioned paths take their
+                                  stream-order ranks from it; nkml_create measures it, the hardware documents no guarantee):
+                                  every partition pass against a stable partition worked out from wavefront ballots, every
+                                  bucket against a copy of the table taken before the batch (per k-mer: count moved by its
+                                  occurrences, as many low flags as the depth leaves room for, none after a high one).  A
+                                  batch that fails returns NKML_E_STATE and leaves the context unusable until nkml_reset.
+                                  Several times slower, one table copy more in memory: for validation runs on new hardware,
+                                  drivers or compilers.  The environment variable NKML_VERIFY_RANKS=1 sets it as well.
+                                  No effect on the atomic path (its ranks come from a sort). */
 
 typedef struct nkml_stats {
     uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */

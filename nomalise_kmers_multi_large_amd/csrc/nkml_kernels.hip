@@ -65,6 +65,7 @@ struct alignas(256) Counters {
     unsigned int bad_bases;       // bytes outside ACGTN seen by the packer
     unsigned int probe_overflow;  // hashed table: a probe sequence wrapped (table full) - must stay 0
     unsigned int hp_left;         // hashed table, partitioned: buckets of the batch that the fast bucket kernel left to the general one
+    unsigned int verify_bad;      // NKML_F_VERIFY_RANKS: elements whose place or flag differs from what the checking kernels work out
 };
 
 struct Slot {
@@ -1307,6 +1308,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 
 #include "nkml_partition.inc"
 #include "nkml_hashpart.inc"
+#include "nkml_verify.inc"
 
 // table dump helpers
 __global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ extra, uint64_t cap, unsigned long long *codes,
@@ -1407,6 +1409,11 @@ struct nkml_ctx {
     bool own_stream;
     bool lds_ordered;       // this device passed k_lds_order_check (ranks may come from returning LDS adds)
     bool broken;            // a batch failed after part of it had been merged into the table: unusable until nkml_reset
+    bool verify;            // NKML_F_VERIFY_RANKS: every partitioned batch is checked by the kernels of nkml_verify.inc
+    void *vf_before;        // ... copy of the table as it was when the batch started
+    uint64_t vf_before_bytes;
+    unsigned long long *vf_keys; // ... hashed table: copy of the second pass's output (the fast bucket kernel queues keys in it)
+    int vf_fault;           // test aid (NKML_TEST_VERIFY_FAULT): damage every batch on purpose
     char err[512];
 
     // table
@@ -1963,6 +1970,51 @@ int run_count_shard(nkml_ctx *c, uint64_t n_words, uint64_t n_bases);
 int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding);
 int collect_partition_timing(nkml_ctx *c);
 
+// NKML_F_VERIFY_RANKS: the table as it is now (the batch has not touched it yet) goes to a buffer of its own
+int verify_snapshot(nkml_ctx *c, const void *table, uint64_t bytes)
+{
+    if (c->vf_before_bytes < bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->vf_before);
+        c->vf_before = nullptr;
+        c->vf_before_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->vf_before, bytes));
+        c->vf_before_bytes = bytes;
+        const size_t vf_lds = 3 * VF_WINDOW * sizeof(uint32_t);
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verify_bucket<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vf_lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verify_bucket<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vf_lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_verify_hbucket), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vf_lds));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->vf_before, table, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->verify_bad, 0, sizeof(unsigned int), c->stream));
+    return NKML_OK;
+}
+
+// ... and after the batch's last kernel: wait, read the tally, fail the batch if anything was out of place
+int verify_verdict(nkml_ctx *c)
+{
+    int rc = fetch_counters(c);
+    if (rc != NKML_OK) return rc;
+    if (c->h_ctr->verify_bad) {
+        c->broken = true; // the batch is in the table, its flags cannot be trusted
+        return fail(c, NKML_E_STATE, "rank verification: %u elements of the batch are not where a stable partition puts them or carry the wrong flag",
+                    c->h_ctr->verify_bad);
+    }
+    return NKML_OK;
+}
+
+// the check of one partition pass (see k_verify_pass); src.keys == nullptr: the keys come from the context's packed words
+template <typename KEY, typename KOUT>
+void verify_pass(nkml_ctx *c, VerifySource src, uint32_t tiles, int shift, const uint32_t *scanned, const KOUT *out, unsigned long long out_mask)
+{
+    if (src.keys)
+        hipLaunchKernelGGL((k_verify_pass<KEY, KOUT, 0>), tiles, 256, 0, c->stream, src, shift, scanned, out, out_mask, c->d_ctr);
+    else if (c->cfg.canonical)
+        hipLaunchKernelGGL((k_verify_pass<KEY, KOUT, 2>), tiles, 256, 0, c->stream, src, shift, scanned, out, out_mask, c->d_ctr);
+    else
+        hipLaunchKernelGGL((k_verify_pass<KEY, KOUT, 1>), tiles, 256, 0, c->stream, src, shift, scanned, out, out_mask, c->d_ctr);
+}
+
 int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
 {
     if (c->broken) return broken_context(c);
@@ -1981,6 +2033,12 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
     const int shift_a = PT_LOWBITS, shift_b = PT_LOWBITS + 8;
     const uint32_t *n_a = c->pt_pad + 256;                 // padded length of the first pass's output, on the device
+    const bool verify = c->verify && !seeding;
+    if (verify) {
+        const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+        int rc = verify_snapshot(c, c->pt_table, entries * (c->pt_wide ? 2 : 1));
+        if (rc != NKML_OK) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -2016,6 +2074,14 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     hipLaunchKernelGGL((k_pt_scatter<uint16_t>), gb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, c->pt_scanB,
                        c->pt_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
+    if (verify) {
+        if (c->vf_fault == 2) hipLaunchKernelGGL(k_verify_fault_swap<uint32_t>, 1, 1, 0, c->stream, c->pt_keysA, n_a);
+        VerifySource sa{d_keys, n, nullptr, c->d_packed, c->d_startbits, n_bases, n_words, k, 0, c->n_shards, c->shard};
+        verify_pass<uint32_t, uint32_t>(c, sa, (uint32_t)ta, shift_a, c->pt_scanA, c->pt_keysA, 0xffffffffull);
+        VerifySource sb{c->pt_keysA, 0, n_a, nullptr, nullptr, 0, 0, k, 0, 1, 0};
+        verify_pass<uint32_t, uint16_t>(c, sb, (uint32_t)tb, shift_b, c->pt_scanB, c->pt_keysB, (1ull << PT_LOWBITS) - 1);
+        HIPCHK(c, hipGetLastError());
+    }
     const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
     const uint32_t depth = (uint32_t)c->cfg.depth;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -2036,6 +2102,17 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
         hipLaunchKernelGGL((k_pt_count_bucket_big<uint8_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
                            (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr, (uint32_t)buckets, big_group);
     HIPCHK(c, hipGetLastError());
+    if (verify) {
+        const size_t vf_lds = 3 * VF_WINDOW * sizeof(uint32_t);
+        if (c->vf_fault == 1) hipLaunchKernelGGL(k_verify_fault_flag, 1, 1, 0, c->stream, c->pt_bounds, (uint32_t)buckets, c->pt_flagsB);
+        if (c->pt_wide)
+            hipLaunchKernelGGL((k_verify_bucket<uint16_t>), (uint32_t)buckets, 512, vf_lds, c->stream, c->pt_keysB, c->pt_bounds, (const uint16_t *)c->pt_table,
+                               (const uint16_t *)c->vf_before, depth, c->pt_flagsB, c->d_ctr);
+        else
+            hipLaunchKernelGGL((k_verify_bucket<uint8_t>), (uint32_t)buckets, 512, vf_lds, c->stream, c->pt_keysB, c->pt_bounds, (const uint8_t *)c->pt_table,
+                               (const uint8_t *)c->vf_before, depth, c->pt_flagsB, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+    }
     if (!seeding) {
         hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
                            c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
@@ -2051,6 +2128,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
         c->pt_timed_keys = n;
         c->pt_timing_pending = true;
     }
+    if (verify) return verify_verdict(c);
     return NKML_OK;
 }
 
@@ -2213,6 +2291,9 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     const uint64_t ta = (n + PT_TILE - 1) / PT_TILE, tb = ta + 256 + 1, ra = ta + 1, rb = tb + 1;
     const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
     const uint32_t *n_a = c->pt_pad + 256;
+    const bool verify = c->verify && !seeding;
+    const HpGeom geo_before = hp_geom(c, c->hp_log2_bucket);
+    if (verify && (rc = verify_snapshot(c, c->hp_table, c->capacity * sizeof(unsigned long long))) != NKML_OK) return rc;
     HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
     if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -2244,6 +2325,16 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     hipLaunchKernelGGL(k_pt_rowscan, cb, PT_ROWSCAN_THREADS, 0, c->stream, c->pt_histB, rb, c->pt_chunks, c->pt_startB, c->pt_scanB);
     hipLaunchKernelGGL((k_hp_scatter<false>), gb, PT_THREADS, 0, c->stream, c->hp_keysA, (uint64_t)0, n_a, HP_SHIFT_B, c->pt_scanB, c->hp_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
+    if (verify) {
+        if (c->vf_fault == 2) hipLaunchKernelGGL(k_verify_fault_swap<unsigned long long>, 1, 1, 0, c->stream, c->hp_keysA, n_a);
+        VerifySource sa{d_keys, n, nullptr, c->d_packed, c->d_startbits, n_bases, n_words, k, 1, 1, 0};
+        verify_pass<unsigned long long, unsigned long long>(c, sa, (uint32_t)ta, HP_SHIFT_A, c->pt_scanA, c->hp_keysA, ~0ull);
+        VerifySource sb{c->hp_keysA, 0, n_a, nullptr, nullptr, 0, 0, k, 0, 1, 0};
+        verify_pass<unsigned long long, unsigned long long>(c, sb, (uint32_t)tb, HP_SHIFT_B, c->pt_scanB, c->hp_keysB, ~0ull);
+        HIPCHK(c, hipGetLastError());
+        if (!c->vf_keys) HIPCHK(c, hipMalloc(&c->vf_keys, c->max_words * 16 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemcpyAsync(c->vf_keys, c->hp_keysB, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    }
     {
         const HpGeom g0 = hp_geom(c, c->hp_log2_bucket);
         HIPCHK(c, hipMemsetAsync(c->hp_done, 0, ((uint64_t)65536 << (g0.log2_bucket - g0.log2_local)) * sizeof(uint32_t), c->stream));
@@ -2286,6 +2377,13 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
         if ((rc = hp_grow(c, true)) != NKML_OK) return rc;
     }
     c->broken = false; // every sub-range of the batch is committed
+    if (verify) {
+        if (c->vf_fault == 1) hipLaunchKernelGGL(k_verify_fault_flag, 1, 1, 0, c->stream, c->pt_bounds, 65536u, c->pt_flagsB);
+        hipLaunchKernelGGL(k_verify_hbucket, 65536u, 512, 3 * VF_WINDOW * sizeof(uint32_t), c->stream, c->vf_keys, c->pt_bounds, c->hp_table,
+                           hp_geom(c, c->hp_log2_bucket), static_cast<const unsigned long long *>(c->vf_before), geo_before, (uint32_t)c->cfg.depth,
+                           c->pt_flagsB, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+    }
 #ifdef HB_STAMP
     hipLaunchKernelGGL(k_hb_stamp_print, 1, 1, 0, c->stream);
 #endif
@@ -2303,6 +2401,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
         c->pt_timed_keys = n;
         c->pt_timing_pending = true;
     }
+    if (verify) return verify_verdict(c);
     return NKML_OK;
 }
 
@@ -2446,6 +2545,11 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         if (cfg->flags & NKML_F_COUNT_ATOMIC) want_hp = false;
         if (can_hp && want_hp) c->partitioned = c->hashpart = true;
     }
+    {
+        const char *env = getenv("NKML_VERIFY_RANKS");
+        c->verify = (cfg->flags & NKML_F_VERIFY_RANKS) != 0 || (env && env[0] == '1');
+        if (const char *f = getenv("NKML_TEST_VERIFY_FAULT")) c->vf_fault = atoi(f);
+    }
     c->n_shards = 1; // (the memset above also wiped the member initialisers)
     c->shard = 0;
     c->key_bytes = c->direct ? 4 : 8;
@@ -2561,6 +2665,7 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
     hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
     hipFree(c->sh_keys); hipFree(c->sh_own); hipFree(c->sh_flags); hipFree(c->sh_tile_count); hipFree(c->sh_tile_base); hipFree(c->sh_scan_tmp);
+    hipFree(c->vf_before); hipFree(c->vf_keys);
     hipFree(c->d_ctr);
     if (c->h_ctr) hipHostFree(c->h_ctr);
     if (c->h_route_starts) hipHostFree(c->h_route_starts);

@@ -1032,6 +1032,82 @@ except Exception as e:
     assert "counting on the atomic path" in out.stderr, out.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,depth,canonical,log2_bucket", [(15, 20, False, None), (15, 300, True, None), (13, 5, False, None),
+                                                          (25, 20, True, None), (25, 4, True, 3), (31, 200, False, (3, 3))])
+def test_rank_verification_mode_passes_and_agrees_with_the_oracle(nk, oracle_lib, k, depth, canonical, log2_bucket):
+    """NKML_F_VERIFY_RANKS: every batch of the partitioned paths is checked on the device by kernels that take no rank from
+    the LDS's lane order (each pass against a ballot-built stable partition, each bucket against a copy of the table from
+    before the batch).  Batches with repeats, crossings, saturated k-mers, growth of the hashed table inside a batch and
+    buckets of several sub-ranges go through it without a complaint, and the results are the oracle's."""
+    from nomalise_kmers_multi_large_amd import binding
+    log2_local = None
+    if isinstance(log2_bucket, tuple):
+        log2_bucket, log2_local = log2_bucket
+    rng = np.random.default_rng(9100 + k + depth)
+    reads = random_reads(rng, 500, k, 4 * k + 40, b"AC") + random_reads(rng, 800, k, 200, b"ACGT", 0.01) \
+        + random_reads(rng, 300, k, 90, b"GT") + [b"A" * 50, b"T" * 77, b"N" * 40] * 3 + [b"G" * 150] * 500
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    o = oracle_lib(k, depth, canonical)
+    want = [o.read(r) for r in reads]
+    saved = {v: os.environ.get(v) for v in ("NKML_HP_LOG2_BUCKET", "NKML_HP_LOG2_LOCAL")}
+    if log2_bucket is not None:
+        os.environ["NKML_HP_LOG2_BUCKET"] = str(log2_bucket)
+    if log2_local is not None:
+        os.environ["NKML_HP_LOG2_LOCAL"] = str(log2_local)
+    try:
+        with nk.KmerNormaliser(k, depth, 0.9, canonical, max_batch_reads=300, max_batch_bases=300 * 200,
+                               flags=binding.NKML_F_COUNT_PARTITIONED | binding.NKML_F_VERIFY_RANKS) as g:
+            assert g.stats()["partitioned"] == 1
+            ok, high, total = g.process_sequence_single(reads)
+            np.testing.assert_array_equal(high, [w[1] for w in want])
+            np.testing.assert_array_equal(total, [w[2] for w in want])
+            assert g.unique_kmers == o.unique
+            if log2_bucket is not None:
+                assert g.stats()["resizes"] > 0
+    finally:
+        for var, val in saved.items():
+            if val is None:
+                os.environ.pop(var, None)
+            else:
+                os.environ[var] = val
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", [1, 2])
+def test_rank_verification_mode_catches_a_damaged_batch(fault):
+    """The checkers have teeth: with one flag of a bucket turned round (fault 1) or two neighbours of the first pass's
+    output swapped (fault 2) - NKML_TEST_VERIFY_FAULT damages every batch this way before the checks run - the batch fails
+    with NKML_E_STATE and the context stays unusable until it is reset.  At k = 15 and at k = 25; a process of its own."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import nomalise_kmers_multi_large_amd as nk
+from nomalise_kmers_multi_large_amd import binding as B, synth
+c1, c2 = next(synth.pair_blocks(1000, seed=5, transcripts=4, block=1000))
+seq, off = synth.interleave(c1, c2)
+for k in (15, 25):
+    with nk.KmerNormaliser(k, 20, 0.9, True, max_batch_reads=4096, max_batch_bases=4096 * 150,
+                           flags=B.NKML_F_COUNT_PARTITIONED | B.NKML_F_VERIFY_RANKS) as g:
+        for attempt in range(2):   # the second call meets the context the first one left unusable
+            try:
+                g.process_batch(seq, off)
+                print("PASSED", k, attempt)
+            except Exception as e:
+                print("CAUGHT", k, attempt, "rank verification" in str(e) or "unusable" in str(e) or "reset" in str(e), "|", e)
+'''
+    env = dict(os.environ, NKML_TEST_VERIFY_FAULT=str(fault))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for k in (15, 25):
+        for attempt in range(2):
+            assert "CAUGHT %d %d True" % (k, attempt) in out.stdout, out.stdout + out.stderr
+    assert "PASSED" not in out.stdout, out.stdout + out.stderr
+
+
 # ---- routing on its own: the whole output against a stable partition computed with numpy ----
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [15, 25])
