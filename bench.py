@@ -456,7 +456,7 @@ def main():
             "data": "synthetic (made on the GPU: synth.gpu_pair_steps)" + (" (REHEARSAL: ranks share one GPU, gloo via host - not a measurement)" if rehearse else ""),
             "config": {"workload": "%d synthetic 150 bp PE pairs per GPU, k=%d%s depth=%d coverage=%g, %s" % (
                 n_pairs, k, " --canonical" if canonical else "", depth, cov, "single device k-mer table" if world == 1 else "k-mer table sharded over %d GPUs (%s)" % (
-                    world, "packed reads all-gathered, every GPU counts its shard" if multi_mode == "replicated" else "RCCL all-to-all of k-mers")),
+                    world, {"replicated": "packed reads all-gathered, every GPU counts its shard", "bucketed": "RCCL all-to-all of bucket-ordered 16-bit k-mer codes, saturated k-mers stay home"}.get(multi_mode, "RCCL all-to-all of k-mers"))),
                 "pairs_per_step": pps, "parallelism": "1 GPU" if world == 1 else "kmer-shard x%d (%s)" % (world, multi_mode),
                 "distinct_steps_of_data": data_steps, "ksize": k, "canonical": bool(canonical), "partitioned": bool(partitioned)},
             "unique_kmers": unique,

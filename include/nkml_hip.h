@@ -220,6 +220,57 @@ int nkml_route_reads_device(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t 
                             uint32_t n_shards, void *d_send_keys, uint32_t *d_send_src, uint64_t *send_counts);
 int nkml_unroute_flags_device(nkml_ctx *ctx, const uint8_t *d_recv_flags, const uint32_t *d_send_src, uint64_t n_sent,
                               uint8_t *d_flags, uint64_t n_keys);
+/*   Ranked routing (no counterpart in the reference; exchange mode's cheaper form of route_reads / unroute_flags, at most
+ *   32 shards): instead of every sent key's base position (4 bytes, in send order) the routing leaves 16 bits per base
+ *   position in d_meta (room for n_bases rounded up to a multiple of 1024) - the shard and the key's rank among the keys
+ *   of its routing tile for that shard, or "no k-mer", or "answered here" - and the tiles' start offsets in every shard's
+ *   segment in d_tile_off (ceil(n / 1024) * n_shards + 1 entries).  nkml_unroute_ranked turns the flags that came back
+ *   (d_back_flags: in send order, like d_recv_flags above) into the flag of every base position with them.  The caller
+ *   keeps d_meta and d_tile_off from the routing of a batch to its way home (batches may overlap: buffers per batch).
+ *   n_home: positions answered by the saturation bitmap (0 without one). */
+int nkml_route_reads_ranked(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases,
+                            uint32_t n_shards, void *d_send_keys, uint16_t *d_meta, uint32_t *d_tile_off, uint64_t *send_counts,
+                            uint64_t *n_home);
+int nkml_unroute_ranked(nkml_ctx *ctx, const uint8_t *d_back_flags, const uint16_t *d_meta, const uint32_t *d_tile_off,
+                        uint64_t n_positions, uint8_t *d_flags);
+/*   Saturation bitmap (no counterpart in the reference; k <= 15 on the partitioned direct table): a k-mer whose count has
+ *   reached depth - 1 at its owner makes every later occurrence "high" whatever is added to it, so such occurrences need
+ *   not travel.  nkml_sat_enable gives the context one bit per k-mer code (4^k / 8 bytes; cleared by nkml_reset), from
+ *   then on nkml_route_reads_ranked answers k-mers whose bit is set where they are read (flag "high", not sent, not
+ *   counted anywhere: nkml_stats adds them to kmers_counted and kmers_saturated of the context that read them; dumped
+ *   counts of such k-mers stop growing).  nkml_sat_collect scans this context's table for k-mers that have reached
+ *   depth - 1 and have no bit yet, sets their bits and writes their codes to d_codes (device memory of the caller; what
+ *   exceeds max_codes is dropped from the list, n_codes = what was written; waits for the stream); nkml_sat_apply sets
+ *   the bits of a list that another rank collected.  A bitmap may lag behind the tables by any number of batches: a k-mer without its bit just
+ *   travels and is counted by its owner as before, results are the same. */
+int nkml_sat_enable(nkml_ctx *ctx);
+int nkml_sat_collect(nkml_ctx *ctx, uint32_t *d_codes, uint64_t max_codes, uint64_t *n_codes);
+int nkml_sat_apply(nkml_ctx *ctx, const uint32_t *d_codes, uint64_t n_codes);
+/*   Bucket-ordered exchange (no counterpart in the reference; k <= 15 on the partitioned direct table; what bucketed.py drives
+ *   with one process per GPU).  Every rank partitions its own batch by table bucket (2^14 k-mer codes each) with the passes of
+ *   the single-GPU path; k-mers travel to their bucket's owner as 16-bit codes within the bucket, bucket after bucket, each
+ *   bucket in stream order; the owner strings the ranks' runs of a bucket together in rank order - the bucket's k-mers of
+ *   the step's global stream (rank 0's reads, then rank 1's, ...) - and counts them with the bucket kernels alone.
+ *   xb_enable  : once per context.  world ranks, this one is `rank`; recv_capacity = most keys that may arrive in one step.
+ *                Buckets are dealt by a fixed pseudo-random permutation (the same on every rank): with B = max(4^k / 2^14, 1)
+ *                buckets, rank r owns those at places [B * r / world, B * (r + 1) / world) of the deal.
+ *   xb_front   : a batch of this rank's reads -> d_send_keys (room for n_bases + 16 keys): the travelling k-mers, owner
+ *                after owner and within an owner bucket after bucket (by place); d_send_counts (B entries): travelling
+ *                k-mers per bucket, by place - the owner of places [a, b) gets entries [a, b); send_totals[r] = keys for
+ *                rank r.  With a saturation bitmap (nkml_sat_enable) k-mers whose bit is set are answered here (n_home of
+ *                them) and do not travel.  Waits for the stream.  Nothing else may use the context's partition buffers
+ *                until xb_finish (one batch under way per context).
+ *   xb_count   : the owner's side.  d_recv_keys: what the ranks sent, rank after rank (n_recv keys in all);
+ *                d_recv_counts: [world][buckets of this rank], the counts that came with them; d_recv_flags (n_recv
+ *                bytes, same order as d_recv_keys): NKML_FLAG_HIGH or 0 per key, to be sent back the way the keys came.
+ *   xb_finish  : d_back_flags: the owners' answers in the order of d_send_keys -> per-read counters of the batch that
+ *                xb_front took (d_offsets, n_reads: the same as there). */
+int nkml_xb_enable(nkml_ctx *ctx, uint32_t world, uint32_t rank, uint64_t recv_capacity);
+int nkml_xb_front(nkml_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, uint16_t *d_send_keys,
+                  uint32_t *d_send_counts, uint64_t *send_totals, uint64_t *n_home);
+int nkml_xb_count(nkml_ctx *ctx, const uint16_t *d_recv_keys, const uint32_t *d_recv_counts, uint64_t n_recv, uint8_t *d_recv_flags);
+int nkml_xb_finish(nkml_ctx *ctx, const uint8_t *d_back_flags, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high, int32_t *d_total);
+
 
 /* The other way to spread one table over a few devices: every device sees every read of a step and counts only
  * the k-mers of its own table shard, so nothing per k-mer crosses a link - only the 2-bit packed reads (one all-gather)

@@ -23,7 +23,7 @@ EXPORTS = [
     "nkml_set_stream", "nkml_synchronize", "nkml_get_stats", "nkml_submit", "nkml_collect", "nkml_process_device",
     "nkml_seed", "nkml_keep_pair", "nkml_keep_single", "nkml_decide_device", "nkml_key_bytes", "nkml_kmerise_device",
     "nkml_count_keys_device", "nkml_seed_keys_device", "nkml_reduce_reads_device", "nkml_dump_table", "nkml_owner_of", "nkml_route_keys_device", "nkml_route_keys_static", "nkml_route_reads_device",
-    "nkml_unroute_flags_device", "nkml_set_shard", "nkml_shard_of", "nkml_pack_device", "nkml_process_packed_device",
+    "nkml_unroute_flags_device", "nkml_route_reads_ranked", "nkml_unroute_ranked", "nkml_sat_enable", "nkml_sat_collect", "nkml_sat_apply", "nkml_xb_enable", "nkml_xb_front", "nkml_xb_count", "nkml_xb_finish", "nkml_set_shard", "nkml_shard_of", "nkml_pack_device", "nkml_process_packed_device",
     "nkml_multi_create", "nkml_multi_destroy", "nkml_multi_last_error", "nkml_multi_device_count", "nkml_multi_reset",
     "nkml_multi_host_staging", "nkml_multi_wait_staged", "nkml_multi_submit", "nkml_multi_collect", "nkml_multi_seed",
     "nkml_multi_get_stats", "nkml_multi_dump_table",
@@ -105,6 +105,15 @@ def load_library():
     lib.nkml_route_keys_static.argtypes = [vp, vp, u64, u32, vp, vp, ctypes.POINTER(u64)]
     lib.nkml_route_reads_device.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, ctypes.POINTER(u64)]
     lib.nkml_unroute_flags_device.argtypes = [vp, vp, vp, u64, vp, u64]
+    lib.nkml_route_reads_ranked.argtypes = [vp, vp, vp, u32, u64, u32, vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.nkml_unroute_ranked.argtypes = [vp, vp, vp, vp, u64, vp]
+    lib.nkml_sat_enable.argtypes = [vp]
+    lib.nkml_sat_collect.argtypes = [vp, vp, u64, ctypes.POINTER(u64)]
+    lib.nkml_sat_apply.argtypes = [vp, vp, u64]
+    lib.nkml_xb_enable.argtypes = [vp, u32, u32, u64]
+    lib.nkml_xb_front.argtypes = [vp, vp, vp, u32, u64, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.nkml_xb_count.argtypes = [vp, vp, vp, u64, vp]
+    lib.nkml_xb_finish.argtypes = [vp, vp, vp, u32, vp, vp]
     lib.nkml_set_shard.argtypes = [vp, u32, u32]
     lib.nkml_shard_of.argtypes = [u64, u32]
     lib.nkml_pack_device.argtypes = [vp, vp, u64, vp]

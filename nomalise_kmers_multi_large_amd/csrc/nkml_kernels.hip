@@ -29,6 +29,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
+#include <algorithm>
 #include <new>
 
 #include <hip/hip_runtime.h>
@@ -65,6 +67,8 @@ struct alignas(256) Counters {
     unsigned int bad_bases;       // bytes outside ACGTN seen by the packer
     unsigned int probe_overflow;  // hashed table: a probe sequence wrapped (table full) - must stay 0
     unsigned int hp_left;         // hashed table, partitioned: buckets of the batch that the fast bucket kernel left to the general one
+    unsigned int route_home;      // ranked routing: positions of the last batch whose k-mer the saturation bitmap answered (not sent)
+    unsigned int sat_new;         // nkml_sat_collect: k-mers found saturated by the last scan
     unsigned int verify_bad;      // NKML_F_VERIFY_RANKS: elements whose place or flag differs from what the checking kernels work out
 };
 
@@ -1060,6 +1064,7 @@ __global__ void __launch_bounds__(256) k_decide(const int32_t *__restrict__ high
 // ------------------------------------------------------------------------------------------------------
 constexpr int ROUTE_TILE = 1024;
 constexpr uint32_t ROUTE_BALLOT_SHARDS = 2; // up to here a ballot per shard and round ranks the keys, beyond it LDS adds do
+constexpr uint32_t ROUTE_META_NONE = 0x8000u, ROUTE_META_HOME = 0x8001u, ROUTE_RANKED_MAX_SHARDS = 32; // (bit 15 free: shard < 32)
 
 __host__ __device__ __forceinline__ uint32_t owner_of(unsigned long long key, uint32_t n_shards)
 {
@@ -1105,9 +1110,21 @@ __device__ __forceinline__ unsigned long long route_key(const RouteSource &src, 
     return i < n ? (unsigned long long)static_cast<const KEY *>(src.keys)[i] : 0ull;
 }
 
+// Ranked routing with a saturation bitmap (sat_bits != nullptr, 32-bit keys): a k-mer whose bit is set has a count of
+// at least depth - 1 at its owner, so every further occurrence is "high" whatever the owner would add - it is answered
+// where it is read and never sent.  The counting pass looks the bits up (one random 4-byte load per k-mer, the only such
+// load of the routing) and leaves them as one 64-bit mask per round of 64 keys for the scatter pass.
+template <typename KEY>
+__device__ __forceinline__ bool route_stays_home(const uint32_t *__restrict__ sat_bits, KEY key)
+{
+    if constexpr (sizeof(KEY) == 4) return key && ((sat_bits[key >> 5] >> (key & 31u)) & 1u);
+    return false;
+}
+
 template <typename KEY, int SRC>
 __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves, int use_adds,
-                                                     uint32_t *__restrict__ hist)
+                                                     uint32_t *__restrict__ hist, const uint32_t *__restrict__ sat_bits,
+                                                     unsigned long long *__restrict__ sat_mask, Counters *ctr)
 {
     __shared__ KEY stage[SRC != 0 ? 4 : 1][SRC != 0 ? ROUTE_STAGE : 1];
     const uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1117,6 +1134,19 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
     int lane = threadIdx.x & 63;
     uint64_t base = wv * ROUTE_TILE;
     uint32_t mine = 0; // lane sh accumulates the count of shard sh (n_shards <= 64: one lane each)
+    unsigned long long home_mask = 0; // lane `it` keeps the mask of round `it`
+    static_assert(ROUTE_TILE / 64 <= 64, "one lane per round for the masks");
+    // the key of (round, lane) as the routing sees it: 0 if there is none or it stays home
+    auto routed_key = [&](int it) {
+        unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+        if (sat_bits) {
+            const bool home = route_stays_home<KEY>(sat_bits, (KEY)key);
+            const unsigned long long m = __ballot(home);
+            if (lane == it) home_mask = m;
+            if (home) key = 0;
+        }
+        return key;
+    };
     if (use_adds) {
         // many shards: one LDS add per key instead of a ballot per shard and round.  Order does not matter for a count, so
         // a shard's counter is spread over `ways` addresses picked by the lane: fewer lanes of an instruction meet at one.
@@ -1125,7 +1155,7 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
         const uint32_t lg = 31u - (uint32_t)__builtin_clz(64u / n_shards), way = (uint32_t)lane & ((1u << lg) - 1u);
         my[lane] = 0; // the wavefront's own row: its LDS instructions run in order
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
-            unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+            unsigned long long key = routed_key(it);
             if (key) atomicAdd(&my[(owner_of(key, n_shards) << lg) | way], 1u);
         }
         wave_lds_handover();
@@ -1133,7 +1163,7 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
             for (uint32_t j = 0; j < (1u << lg); j++) mine += __hip_atomic_load(&my[((uint32_t)lane << lg) | j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
-            unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+            unsigned long long key = routed_key(it);
             uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
             for (uint32_t sh = 0; sh < n_shards; sh++) {
                 unsigned long long m = __ballot(own == sh);
@@ -1142,13 +1172,23 @@ __global__ void __launch_bounds__(256) k_route_count(RouteSource src, uint64_t n
         }
     }
     if ((uint32_t)lane < n_shards) hist[(uint64_t)lane * n_waves + wv] = mine;
+    if (sat_bits) {
+        if (lane < ROUTE_TILE / 64) sat_mask[wv * (ROUTE_TILE / 64) + lane] = home_mask;
+        const uint32_t stayed = wave_sum((uint32_t)__popcll(home_mask));
+        if (lane == 0 && stayed) atomicAdd(&ctr->route_home, stayed);
+    }
 }
 
 template <typename KEY, int SRC>
 __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t n, uint32_t n_shards, uint64_t n_waves, int use_adds,
                                                        const uint32_t *__restrict__ offsets, KEY *__restrict__ send_keys,
-                                                       uint32_t *__restrict__ send_src)
+                                                       uint32_t *__restrict__ send_src, const unsigned long long *__restrict__ sat_mask,
+                                                       uint16_t *__restrict__ meta_out)
 {
+    // meta_out != nullptr (ranked routing, at most 32 shards): instead of every sent key's base position (send_src, 4 bytes,
+    // in send order) the pass leaves 16 bits per base position, in base order: shard << 10 | rank among the tile's keys of
+    // that shard, ROUTE_META_NONE where there is no k-mer, ROUTE_META_HOME where the k-mer stayed home (sat_mask).  With
+    // the tile's start in every shard's segment (offsets: kept by the caller) that is where the key's flag comes back to.
     __shared__ KEY stage[SRC != 0 ? 4 : 1][SRC != 0 ? ROUTE_STAGE : 1];
     const uint64_t wv = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool live_wave = wv < n_waves;
@@ -1157,6 +1197,9 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
     int lane = threadIdx.x & 63;
     uint64_t base = wv * ROUTE_TILE;
     uint32_t next = (uint32_t)lane < n_shards ? offsets[(uint64_t)lane * n_waves + wv] : 0u; // lane sh: next free slot of shard sh
+    const uint32_t first = next;
+    unsigned long long home_word = sat_mask && lane < ROUTE_TILE / 64 ? sat_mask[wv * (ROUTE_TILE / 64) + lane] : 0ull; // lane `it`: round `it`
+    auto stays_home = [&](int it) { return (bool)((__shfl(home_word, it) >> lane) & 1ull); };
     if (use_adds) {
         // many shards: the tile's keys are first brought into shard order inside LDS and leave as one run per shard, so that
         // neighbouring lanes write neighbouring addresses instead of a few keys here and a few there.  One returning add per
@@ -1177,12 +1220,15 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
         my[lane] = 0; // the wavefront's own row: its LDS instructions run in order
 #pragma unroll
         for (int it = 0; it < ROUTE_TILE / 64; it++) {
-            uint32_t v = 0;
+            uint32_t v = 0, m16 = ROUTE_META_NONE;
+            if (sat_mask && stays_home(it)) { kk[it] = 0; m16 = ROUTE_META_HOME; }
             if (kk[it]) {
                 const uint32_t own = owner_of(kk[it], n_shards);
                 v = atomicAdd(&my[own], 1u) | (own << 10);
+                m16 = v;
             }
             rk[it >> 1] = (it & 1) ? (rk[it >> 1] | (v << 16)) : v;
+            if (meta_out) meta_out[base + it * 64 + lane] = (uint16_t)m16;
         }
         wave_lds_handover();
         const uint32_t c = __hip_atomic_load(&my[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1210,23 +1256,61 @@ __global__ void __launch_bounds__(256) k_route_scatter(RouteSource src, uint64_t
         for (uint32_t at = lane; at < total; at += 64) {
             const uint32_t m = meta[w][at], dst = gdst[w][m >> 10] + at;
             send_keys[dst] = okey[at];
-            send_src[dst] = (uint32_t)(base + (m & 1023u));
+            if (!meta_out) send_src[dst] = (uint32_t)(base + (m & 1023u));
         }
         return;
     }
     for (int it = 0; it < ROUTE_TILE / 64; it++) {
         uint64_t i = base + it * 64 + lane;
         unsigned long long key = route_key<KEY, SRC>(src, stage[SRC != 0 ? threadIdx.x >> 6 : 0], base, it, lane, n);
+        uint32_t m16 = ROUTE_META_NONE;
+        if (sat_mask && stays_home(it)) { key = 0; m16 = ROUTE_META_HOME; }
         uint32_t own = key ? owner_of(key, n_shards) : 0xffffffffu;
         uint32_t dst = 0;
         for (uint32_t sh = 0; sh < n_shards; sh++) {
             unsigned long long m = __ballot(own == sh);
-            uint32_t start = __shfl(next, (int)sh);
-            if (own == sh) dst = start + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+            uint32_t start = __shfl(next, (int)sh), start0 = __shfl(first, (int)sh);
+            if (own == sh) {
+                dst = start + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                m16 = (own << 10) | (dst - start0);
+            }
             if ((uint32_t)lane == sh) next += (uint32_t)__popcll(m);
         }
-        if (key) { send_keys[dst] = (KEY)key; send_src[dst] = (uint32_t)i; }
+        if (key) {
+            send_keys[dst] = (KEY)key;
+            if (!meta_out) send_src[dst] = (uint32_t)i;
+        }
+        if (meta_out) meta_out[i] = (uint16_t)m16;
     }
+}
+
+// Ranked routing's way home: flags[e] of every base position from what the scatter pass left there.  Eight positions per
+// lane: one 16-byte load, eight single-byte gathers (neighbours of one shard read neighbouring bytes), one 8-byte store.
+__global__ void __launch_bounds__(256) k_unroute_ranked(const uint8_t *__restrict__ back_flags, const uint16_t *__restrict__ meta,
+                                                        const uint32_t *__restrict__ offsets, uint64_t n_waves, uint64_t n_positions,
+                                                        uint8_t *__restrict__ flags)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 8;
+    for (uint64_t e0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8; e0 < n_positions; e0 += stride) { // n_positions: a multiple of 16
+        const uint4 mv = *reinterpret_cast<const uint4 *>(meta + e0);
+        const uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w};
+        const uint64_t tile = e0 >> 10; // ROUTE_TILE = 1024 positions, eight consecutive ones share it
+        uint32_t f[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t m = (mw[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            if (m & 0x8000u) f[j] = m == ROUTE_META_HOME ? FLAG_HIGH : FLAG_NONE;
+            else f[j] = back_flags[offsets[(uint64_t)(m >> 10) * n_waves + tile] + (m & 1023u)];
+        }
+        *reinterpret_cast<uint2 *>(flags + e0) = make_uint2(f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24), f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24));
+    }
+}
+
+// the bits of a list of k-mers that another rank found saturated (k_sat_collect)
+__global__ void __launch_bounds__(256) k_sat_apply(const uint32_t *__restrict__ codes, uint64_t n, uint32_t *__restrict__ sat_bits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) atomicOr(&sat_bits[codes[i] >> 5], 1u << (codes[i] & 31u));
 }
 
 // flags that came back from the owners, in the order the keys were sent, go back to their base positions
@@ -1309,6 +1393,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 #include "nkml_partition.inc"
 #include "nkml_hashpart.inc"
 #include "nkml_verify.inc"
+#include "nkml_bucketed.inc"
 
 // table dump helpers
 __global__ void __launch_bounds__(256) k_dump_direct(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ extra, uint64_t cap, unsigned long long *codes,
@@ -1476,6 +1561,21 @@ struct nkml_ctx {
 
     // routing scratch (sharded path), allocated on first use
     uint32_t *d_route_hist, *d_route_off;
+    uint32_t *sat_bits;             // nkml_sat_enable: one bit per k-mer code, set = known to have reached depth - 1 at its owner
+    unsigned long long *d_sat_mask; // ... per routing tile and round: which of the 64 positions stayed home
+    uint64_t sat_mask_words;
+    uint64_t route_home_total;      // positions answered by the bitmap since create / reset
+    // bucket-ordered exchange (nkml_xb_enable): the deal of buckets to ranks, the sender's and the owner's buffers
+    uint32_t xb_world, xb_rank, xb_buckets;
+    uint32_t *xb_order, *xb_place;  // bucket at place i / place of bucket b
+    uint32_t *xb_kept, *xb_base;    // sender: travelling keys per place, their exclusive scan (xb_buckets + 1 entries)
+    uint32_t *xb_sizes, *xb_bounds2, *xb_run_at; // owner: keys per bucket, their scan; where every received run starts
+    uint16_t *xb_keys2;             // owner: what arrived, in bucket order
+    uint8_t *xb_flags2;
+    uint64_t xb_capacity;           // keys the owner's buffers hold
+    void *xb_scan_tmp;
+    size_t xb_scan_tmp_bytes;
+    uint64_t xb_n;                  // positions of the batch between nkml_xb_front and nkml_xb_finish (0 = none under way)
     uint64_t route_entries;
     void *d_route_tmp;
     size_t route_tmp_bytes;
@@ -1671,6 +1771,8 @@ int clear_table(nkml_ctx *c)
         HIPCHK(c, zero_device(c->slots, c->capacity * sizeof(Slot), c->stream));
     }
     if (c->filter) HIPCHK(c, hipMemsetAsync(c->filter, 0, FILTER_WORDS * sizeof(uint32_t), c->stream));
+    if (c->sat_bits) HIPCHK(c, zero_device(c->sat_bits, (c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity) / 8, c->stream));
+    c->route_home_total = 0;
     HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->crossing_kmers = c->crossing_occ = 0;
     c->count_ms = 0;
@@ -2015,33 +2117,17 @@ void verify_pass(nkml_ctx *c, VerifySource src, uint32_t tiles, int shift, const
         hipLaunchKernelGGL((k_verify_pass<KEY, KOUT, 1>), tiles, 256, 0, c->stream, src, shift, scanned, out, out_mask, c->d_ctr);
 }
 
-int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
+// The two partition passes of the direct table's path: the batch's k-mers (from d_keys, or recomputed from the context's
+// packed words) end up in pt_keysB grouped by bucket, each bucket in stream order; what the reverse passes need stays in
+// pt_sposA / pt_sposB (not when seeding) and the histograms.
+static int pt_forward(nkml_ctx *c, const uint32_t *d_keys, uint64_t n, uint64_t n_bases, bool seeding)
 {
-    if (c->broken) return broken_context(c);
-    if (n == 0) return NKML_OK;
-    if (c->hashpart) return run_count_hashpart(c, static_cast<const unsigned long long *>(d_keys_any), n, n_bases, d_flags, seeding);
-    const uint32_t *d_keys = static_cast<const uint32_t *>(d_keys_any);
-    if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
-    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
-    if (profile && c->pt_timing_pending) { // the events are about to be recorded again: read the last batch's first
-        int rc = collect_partition_timing(c);
-        if (rc != NKML_OK) return rc;
-    }
     const uint64_t ta = (n + PT_TILE - 1) / PT_TILE;       // first-pass tiles of this batch
     const uint64_t tb = ta + 256 + 1;                      // bound on second-pass tiles (each group padded to a tile)
     const uint64_t ra = ta + 1, rb = tb + 1;               // histogram rows: the tiles and the all-zero row after them
     const uint32_t ca = (uint32_t)((ra + PT_CH - 1) / PT_CH), cb = (uint32_t)((rb + PT_CH - 1) / PT_CH);
     const int shift_a = PT_LOWBITS, shift_b = PT_LOWBITS + 8;
     const uint32_t *n_a = c->pt_pad + 256;                 // padded length of the first pass's output, on the device
-    const bool verify = c->verify && !seeding;
-    if (verify) {
-        const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
-        int rc = verify_snapshot(c, c->pt_table, entries * (c->pt_wide ? 2 : 1));
-        if (rc != NKML_OK) return rc;
-    }
-    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
-    if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     const uint64_t n_words = n / 16;
     const int k = c->cfg.ksize;
     uint32_t *spos_a = seeding ? nullptr : c->pt_sposA, *spos_b = seeding ? nullptr : c->pt_sposB;
@@ -2074,6 +2160,73 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     hipLaunchKernelGGL((k_pt_scatter<uint16_t>), gb, PT_THREADS, 0, c->stream, c->pt_keysA, (uint64_t)0, n_a, shift_b, c->pt_scanB,
                        c->pt_keysB, spos_b);
     HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+// The reverse passes: the flags in pt_flagsB (one per element of pt_keysB) go back to base positions - to d_flags (one byte
+// each), or, with d_flags == nullptr, to the context's word flags.
+static int pt_backward(nkml_ctx *c, uint64_t n, uint8_t *d_flags)
+{
+    const uint64_t ta = (n + PT_TILE - 1) / PT_TILE, tb = ta + 256 + 1;
+    const uint32_t ga = (uint32_t)((ta + 7) / 8 * 8), gb = (uint32_t)((tb + 7) / 8 * 8);
+    const uint32_t *n_a = c->pt_pad + 256;
+    hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
+                       c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_pt_ungather, ga, PU_THREADS, 0, c->stream, c->pt_sposA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
+                       c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW, d_flags ? (uint32_t *)nullptr : c->d_wflags);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+// The bucket kernels over keys grouped by bucket (keysB with bounds[b] .. bounds[b + 1] for bucket b): counts into the table,
+// one flag per key into flagsB, tallies into the counters.
+static int pt_count_buckets(nkml_ctx *c, const uint16_t *keysB, const uint32_t *bounds, uint8_t *flagsB, bool seeding, bool profile)
+{
+    const uint64_t buckets = (c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1;
+    const uint32_t depth = (uint32_t)c->cfg.depth;
+    if (c->pt_wide)
+        hipLaunchKernelGGL((k_pt_count_bucket<uint16_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, keysB, bounds,
+                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, flagsB, c->pt_tally);
+    else
+        hipLaunchKernelGGL((k_pt_count_bucket<uint8_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, keysB, bounds,
+                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, flagsB, c->pt_tally);
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    hipLaunchKernelGGL(k_pt_tally_reduce, (uint32_t)((buckets + 1023) / 1024 < 64 ? (buckets + 1023) / 1024 : 64), 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
+    const uint32_t big_group = buckets >= 256 * 1024 ? 256u : buckets >= 2048 ? (uint32_t)(buckets / 1024) : 1u;
+    if (c->pt_wide)
+        hipLaunchKernelGGL((k_pt_count_bucket_big<uint16_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, keysB, bounds,
+                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, flagsB, c->d_ctr, (uint32_t)buckets, big_group);
+    else
+        hipLaunchKernelGGL((k_pt_count_bucket_big<uint8_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, keysB, bounds,
+                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, flagsB, c->d_ctr, (uint32_t)buckets, big_group);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint64_t n_bases, uint8_t *d_flags, bool seeding)
+{
+    if (c->broken) return broken_context(c);
+    if (n == 0) return NKML_OK;
+    if (c->hashpart) return run_count_hashpart(c, static_cast<const unsigned long long *>(d_keys_any), n, n_bases, d_flags, seeding);
+    const uint32_t *d_keys = static_cast<const uint32_t *>(d_keys_any);
+    if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
+    const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
+    int rc;
+    if (profile && c->pt_timing_pending && (rc = collect_partition_timing(c)) != NKML_OK) return rc; // the events are about to be recorded again
+    const uint64_t ta = (n + PT_TILE - 1) / PT_TILE, tb = ta + 256 + 1;
+    const int shift_a = PT_LOWBITS, shift_b = PT_LOWBITS + 8;
+    const uint32_t *n_a = c->pt_pad + 256;
+    const uint64_t n_words = n / 16;
+    const int k = c->cfg.ksize;
+    const bool verify = c->verify && !seeding;
+    if (verify) {
+        const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+        if ((rc = verify_snapshot(c, c->pt_table, entries * (c->pt_wide ? 2 : 1))) != NKML_OK) return rc;
+    }
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
+    if (profile) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if ((rc = pt_forward(c, d_keys, n, n_bases, seeding)) != NKML_OK) return rc;
     if (verify) {
         if (c->vf_fault == 2) hipLaunchKernelGGL(k_verify_fault_swap<uint32_t>, 1, 1, 0, c->stream, c->pt_keysA, n_a);
         VerifySource sa{d_keys, n, nullptr, c->d_packed, c->d_startbits, n_bases, n_words, k, 0, c->n_shards, c->shard};
@@ -2086,22 +2239,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     const uint32_t depth = (uint32_t)c->cfg.depth;
     if (profile) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_pt_bucket_bounds, (uint32_t)(buckets / 256 + 1), 256, 0, c->stream, c->pt_scanB, c->pt_pad, (uint32_t)buckets, c->pt_bounds);
-    if (c->pt_wide)
-        hipLaunchKernelGGL((k_pt_count_bucket<uint16_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_bounds,
-                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
-    else
-        hipLaunchKernelGGL((k_pt_count_bucket<uint8_t>), (uint32_t)buckets, PB_THREADS, 0, c->stream, c->pt_keysB, c->pt_bounds,
-                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->pt_tally);
-    if (profile) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(k_pt_tally_reduce, (uint32_t)((buckets + 1023) / 1024 < 64 ? (buckets + 1023) / 1024 : 64), 1024, 0, c->stream, c->pt_tally, (uint32_t)buckets, c->d_ctr);
-    const uint32_t big_group = buckets >= 256 * 1024 ? 256u : buckets >= 2048 ? (uint32_t)(buckets / 1024) : 1u;
-    if (c->pt_wide)
-        hipLaunchKernelGGL((k_pt_count_bucket_big<uint16_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
-                           (uint16_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr, (uint32_t)buckets, big_group);
-    else
-        hipLaunchKernelGGL((k_pt_count_bucket_big<uint8_t>), (uint32_t)((buckets + big_group - 1) / big_group), 256, 65536, c->stream, c->pt_keysB, c->pt_scanB, c->pt_pad,
-                           (uint8_t *)c->pt_table, depth, seeding ? 1 : 0, c->pt_flagsB, c->d_ctr, (uint32_t)buckets, big_group);
-    HIPCHK(c, hipGetLastError());
+    if ((rc = pt_count_buckets(c, c->pt_keysB, c->pt_bounds, c->pt_flagsB, seeding, profile)) != NKML_OK) return rc;
     if (verify) {
         const size_t vf_lds = 3 * VF_WINDOW * sizeof(uint32_t);
         if (c->vf_fault == 1) hipLaunchKernelGGL(k_verify_fault_flag, 1, 1, 0, c->stream, c->pt_bounds, (uint32_t)buckets, c->pt_flagsB);
@@ -2113,13 +2251,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
                                (const uint8_t *)c->vf_before, depth, c->pt_flagsB, c->d_ctr);
         HIPCHK(c, hipGetLastError());
     }
-    if (!seeding) {
-        hipLaunchKernelGGL(k_pt_ungather, gb, PU_THREADS, 0, c->stream, c->pt_sposB, (uint64_t)0, n_a, c->pt_histB, c->pt_scanB,
-                           c->pt_flagsB, c->pt_flagsA, (uint8_t)0, (uint32_t *)nullptr);
-        hipLaunchKernelGGL(k_pt_ungather, ga, PU_THREADS, 0, c->stream, c->pt_sposA, n, (const uint32_t *)nullptr, c->pt_histA, c->pt_scanA,
-                           c->pt_flagsA, d_flags, (uint8_t)FLAG_LOW, d_flags ? (uint32_t *)nullptr : c->d_wflags);
-        HIPCHK(c, hipGetLastError());
-    }
+    if (!seeding && (rc = pt_backward(c, n, d_flags)) != NKML_OK) return rc;
 #ifdef PB_STAMP
     hipLaunchKernelGGL(k_pt_stamp_print, 1, 1, 0, c->stream, (uint32_t)buckets);
 #endif
@@ -2664,6 +2796,9 @@ void nkml_destroy(nkml_ctx *c)
     hipFree(c->d_wflags); hipFree(c->d_high); hipFree(c->d_total);
     hipFree(c->d_list_sat); hipFree(c->d_list_cross); hipFree(c->d_occ); hipFree(c->d_occ_sorted); hipFree(c->d_sort_tmp);
     hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
+    hipFree(c->sat_bits); hipFree(c->d_sat_mask);
+    hipFree(c->xb_order); hipFree(c->xb_place); hipFree(c->xb_kept); hipFree(c->xb_base); hipFree(c->xb_sizes); hipFree(c->xb_bounds2);
+    hipFree(c->xb_run_at); hipFree(c->xb_keys2); hipFree(c->xb_flags2); hipFree(c->xb_scan_tmp);
     hipFree(c->sh_keys); hipFree(c->sh_own); hipFree(c->sh_flags); hipFree(c->sh_tile_count); hipFree(c->sh_tile_base); hipFree(c->sh_scan_tmp);
     hipFree(c->vf_before); hipFree(c->vf_keys);
     hipFree(c->d_ctr);
@@ -2726,8 +2861,9 @@ int nkml_get_stats(nkml_ctx *c, nkml_stats *out)
     out->unique_kmers = c->h_ctr->unique;
     out->capacity = c->capacity;
     out->table_bytes = c->hashpart ? c->capacity * sizeof(unsigned long long) : c->partitioned ? c->capacity * (c->pt_wide ? 2 : 1) : c->direct ? c->capacity * 4 + c->capacity / 8 : c->capacity * sizeof(Slot);
-    out->kmers_counted = c->h_ctr->counted;
-    out->kmers_saturated = c->h_ctr->saturated;
+    // (occurrences the saturation bitmap answered where they were read never reached a table: they count as saturated here)
+    out->kmers_counted = c->h_ctr->counted + c->route_home_total;
+    out->kmers_saturated = c->h_ctr->saturated + c->route_home_total;
     out->crossing_kmers = c->h_ctr->total_cross;
     out->crossing_occurrences = c->crossing_occ;
     out->resizes = c->resizes;
@@ -3015,8 +3151,10 @@ int nkml_owner_of(uint64_t key, uint32_t n_shards) { return n_shards ? (int)owne
 // words the context prepared (n_bases of them).
 // hist / off: (tiles x shards + 1) entries each.  sums == nullptr: the scan is rocPRIM's, with the context's temporary
 // storage; else the three-launch scan above with `sums` for its block totals (nothing that could allocate).
+// meta != nullptr: ranked routing (see k_route_scatter), d_send_src unused; sat_bits != nullptr: with the saturation bitmap.
 static int route_run(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t n_bases, uint32_t n_shards, void *d_send_keys,
-                     uint32_t *d_send_src, uint64_t *send_counts, uint32_t *hist, uint32_t *off, uint32_t *sums)
+                     uint32_t *d_send_src, uint64_t *send_counts, uint32_t *hist, uint32_t *off, uint32_t *sums,
+                     uint16_t *meta = nullptr, const uint32_t *sat_bits = nullptr, unsigned long long *sat_mask = nullptr)
 {
     const uint64_t n_waves = (n_keys + ROUTE_TILE - 1) / ROUTE_TILE;
     const uint64_t entries = n_waves * n_shards;
@@ -3026,9 +3164,9 @@ static int route_run(nkml_ctx *c, const void *d_keys, uint64_t n_keys, uint64_t 
     const int mode = d_keys ? 0 : c->cfg.canonical ? 2 : 1;
     // beyond two shards one LDS add per key ranks it (where the device serves such adds in lane order: checked at nkml_create)
     const int use_adds = n_shards > ROUTE_BALLOT_SHARDS && c->lds_ordered;
-#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, hist)
+#define ROUTE_COUNT(KEY, SRC) hipLaunchKernelGGL((k_route_count<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, hist, sat_bits, sat_mask, c->d_ctr)
 #define ROUTE_SCATTER(KEY, SRC) hipLaunchKernelGGL((k_route_scatter<KEY, SRC>), grid, 256, 0, c->stream, src, n_keys, n_shards, n_waves, use_adds, off, \
-                                                   (KEY *)d_send_keys, d_send_src)
+                                                   (KEY *)d_send_keys, d_send_src, sat_bits ? sat_mask : nullptr, meta)
 #define ROUTE_DISPATCH(WHAT)                                                                                      \
     do {                                                                                                          \
         if (c->key_bytes == 4) { if (mode == 0) WHAT(uint32_t, 0); else if (mode == 1) WHAT(uint32_t, 1); else WHAT(uint32_t, 2); } \
@@ -3138,6 +3276,258 @@ int nkml_unroute_flags_device(nkml_ctx *c, const uint8_t *d_recv_flags, const ui
         HIPCHK(c, hipGetLastError());
     }
     return NKML_OK;
+}
+
+// ---- ranked routing and the saturation bitmap (exchange mode) -----------------------------------------------------------
+// first place of rank r in the deal of the bucket-ordered exchange
+static uint32_t xb_first(uint32_t buckets, uint32_t world, uint32_t r) { return (uint32_t)((uint64_t)buckets * r / world); }
+
+int nkml_sat_enable(nkml_ctx *c)
+{
+    if (!c) return NKML_E_ARG;
+    if (!c->partitioned || c->hashpart) return fail(c, NKML_E_STATE, "the saturation bitmap needs the partitioned direct table (k <= 15)");
+    if (c->sat_bits) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+    HIPCHK(c, hipMalloc(&c->sat_bits, entries / 8));
+    HIPCHK(c, hipMemsetAsync(c->sat_bits, 0, entries / 8, c->stream));
+    return NKML_OK;
+}
+
+int nkml_route_reads_ranked(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, uint32_t n_shards,
+                            void *d_send_keys, uint16_t *d_meta, uint32_t *d_tile_off, uint64_t *send_counts, uint64_t *n_home)
+{
+    if (!c || !d_seq || !d_offsets || !d_send_keys || !d_meta || !d_tile_off || !send_counts || n_shards == 0 || n_shards > ROUTE_RANKED_MAX_SHARDS)
+        return NKML_E_ARG;
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    for (uint32_t s = 0; s < n_shards; s++) send_counts[s] = 0;
+    if (n_home) *n_home = 0;
+    if (n_reads == 0) return NKML_OK;
+    const uint64_t n_keys = (n_bases + 15) / 16 * 16;
+    if (n_keys >= (1ull << 32)) return fail(c, NKML_E_ARG, "too many keys for 32-bit positions");
+    const uint64_t n_waves = (n_keys + ROUTE_TILE - 1) / ROUTE_TILE, entries = n_waves * n_shards;
+    if (entries >= (1ull << 31)) return fail(c, NKML_E_ARG, "routing table too large");
+    if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+    if (entries + 1 > c->route_entries) { // the counts and the scan's temporary storage; the offsets go to the caller's d_tile_off
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_route_hist); hipFree(c->d_route_off); hipFree(c->d_route_tmp);
+        c->d_route_hist = c->d_route_off = nullptr; c->d_route_tmp = nullptr;
+        c->route_entries = entries + 1;
+        HIPCHK(c, hipMalloc(&c->d_route_hist, c->route_entries * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc(&c->d_route_off, c->route_entries * sizeof(uint32_t)));
+        size_t tmp = 0;
+        HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, c->d_route_hist, c->d_route_off, 0u, (size_t)c->route_entries, rocprim::plus<uint32_t>(), c->stream));
+        c->route_tmp_bytes = tmp ? tmp : 256;
+        HIPCHK(c, hipMalloc(&c->d_route_tmp, c->route_tmp_bytes));
+    }
+    if (c->sat_bits && n_waves * (ROUTE_TILE / 64) > c->sat_mask_words) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->d_sat_mask);
+        c->d_sat_mask = nullptr;
+        c->sat_mask_words = n_waves * (ROUTE_TILE / 64);
+        HIPCHK(c, hipMalloc(&c->d_sat_mask, c->sat_mask_words * sizeof(unsigned long long)));
+    }
+    if (c->sat_bits) HIPCHK(c, hipMemsetAsync(&c->d_ctr->route_home, 0, sizeof(unsigned int), c->stream));
+    if ((rc = route_run(c, nullptr, n_keys, n_bases, n_shards, d_send_keys, nullptr, send_counts, c->d_route_hist, d_tile_off, nullptr, d_meta,
+                        c->sat_bits, c->d_sat_mask)) != NKML_OK)
+        return rc;
+    if ((rc = fetch_counters(c)) != NKML_OK) return rc; // the stream has been waited for: the tallies are final
+    c->route_home_total += c->h_ctr->route_home;
+    if (n_home) *n_home = c->sat_bits ? c->h_ctr->route_home : 0;
+    return check_bad_bases(c);
+}
+
+int nkml_unroute_ranked(nkml_ctx *c, const uint8_t *d_back_flags, const uint16_t *d_meta, const uint32_t *d_tile_off, uint64_t n_positions,
+                        uint8_t *d_flags)
+{
+    if (!c || !d_meta || !d_tile_off || !d_flags || (n_positions & 15u)) return NKML_E_ARG;
+    if (n_positions == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t n_waves = (n_positions + ROUTE_TILE - 1) / ROUTE_TILE;
+    hipLaunchKernelGGL(k_unroute_ranked, blocks_for((n_positions + 7) / 8), 256, 0, c->stream, d_back_flags, d_meta, d_tile_off, n_waves, n_positions, d_flags);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int nkml_sat_collect(nkml_ctx *c, uint32_t *d_codes, uint64_t max_codes, uint64_t *n_codes)
+{
+    if (!c || !n_codes || (max_codes && !d_codes) || max_codes >= (1ull << 32)) return NKML_E_ARG;
+    if (!c->sat_bits) return fail(c, NKML_E_STATE, "nkml_sat_enable first");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->sat_new, 0, sizeof(unsigned int), c->stream));
+    // the buckets of the table this context counts into: all of them, or those it owns in the bucket-ordered exchange
+    uint32_t grid = (uint32_t)(entries >> PT_LOWBITS), first = 0;
+    if (c->xb_order) {
+        first = xb_first(c->xb_buckets, c->xb_world, c->xb_rank);
+        grid = xb_first(c->xb_buckets, c->xb_world, c->xb_rank + 1) - first;
+    }
+    if (c->pt_wide)
+        hipLaunchKernelGGL((k_sat_collect<uint16_t>), grid, 256, 0, c->stream, (const uint16_t *)c->pt_table, c->xb_order, first, (uint32_t)c->cfg.depth, c->sat_bits,
+                           d_codes, (uint32_t)max_codes, c->d_ctr);
+    else
+        hipLaunchKernelGGL((k_sat_collect<uint8_t>), grid, 256, 0, c->stream, (const uint8_t *)c->pt_table, c->xb_order, first, (uint32_t)c->cfg.depth, c->sat_bits,
+                           d_codes, (uint32_t)max_codes, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    if (int rc = fetch_counters(c)) return rc;
+    // More than the list holds: the bits are set here, the list only feeds other ranks' bitmaps, which may lag for good -
+    // what did not fit stays a travelling k-mer on the other ranks (results do not depend on it).
+    *n_codes = c->h_ctr->sat_new < max_codes ? c->h_ctr->sat_new : max_codes;
+    return NKML_OK;
+}
+
+int nkml_sat_apply(nkml_ctx *c, const uint32_t *d_codes, uint64_t n_codes)
+{
+    if (!c || (n_codes && !d_codes)) return NKML_E_ARG;
+    if (!c->sat_bits) return fail(c, NKML_E_STATE, "nkml_sat_enable first");
+    if (n_codes == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(k_sat_apply, blocks_for(n_codes), 256, 0, c->stream, d_codes, n_codes, c->sat_bits);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+// ---- bucket-ordered exchange (see nkml_bucketed.inc) ---------------------------------------------------------------------
+
+int nkml_xb_enable(nkml_ctx *c, uint32_t world, uint32_t rank, uint64_t recv_capacity)
+{
+    if (!c || world == 0 || rank >= world) return NKML_E_ARG;
+    if (!c->partitioned || c->hashpart) return fail(c, NKML_E_STATE, "the bucket-ordered exchange needs the partitioned direct table (k <= 15)");
+    if (c->n_shards > 1) return fail(c, NKML_E_STATE, "the context counts a table shard of its own (nkml_set_shard)");
+    if (c->xb_order) return fail(c, NKML_E_STATE, "nkml_xb_enable was called before");
+    const uint32_t buckets = (uint32_t)((c->capacity >> PT_LOWBITS) ? (c->capacity >> PT_LOWBITS) : 1);
+    if (buckets < world) return fail(c, NKML_E_ARG, "%u buckets cannot be dealt to %u ranks", buckets, world);
+    if (recv_capacity >= (1ull << 32)) return fail(c, NKML_E_ARG, "more keys than 32-bit positions address");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // the deal: buckets in the order of a mixed value of their number (the same on every rank)
+    std::vector<uint32_t> order(buckets), place(buckets);
+    for (uint32_t b = 0; b < buckets; b++) order[b] = b;
+    auto mixed = [](uint32_t b) { // (a finaliser of its own: the deal must not change if a table's hash does)
+        uint64_t x = (uint64_t)b + 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        return x ^ (x >> 31);
+    };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        const uint64_t ma = mixed(a), mb = mixed(b);
+        return ma != mb ? ma < mb : a < b;
+    });
+    for (uint32_t i = 0; i < buckets; i++) place[order[i]] = i;
+    const uint32_t mine = xb_first(buckets, world, rank + 1) - xb_first(buckets, world, rank);
+    HIPCHK(c, hipMalloc(&c->xb_order, buckets * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_place, buckets * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_kept, ((uint64_t)buckets + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_base, ((uint64_t)buckets + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_sizes, ((uint64_t)buckets + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_bounds2, ((uint64_t)buckets + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_run_at, ((uint64_t)world * mine + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&c->xb_keys2, (recv_capacity + 16) * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc(&c->xb_flags2, recv_capacity + 16));
+    size_t t1 = 0, t2 = 0;
+    HIPCHK(c, rocprim::exclusive_scan(nullptr, t1, c->xb_kept, c->xb_base, 0u, (size_t)buckets + 1, rocprim::plus<uint32_t>(), c->stream));
+    HIPCHK(c, rocprim::exclusive_scan(nullptr, t2, c->xb_run_at, c->xb_run_at, 0u, (size_t)world * mine + 1, rocprim::plus<uint32_t>(), c->stream));
+    c->xb_scan_tmp_bytes = (t1 > t2 ? t1 : t2) + 256;
+    HIPCHK(c, hipMalloc(&c->xb_scan_tmp, c->xb_scan_tmp_bytes));
+    HIPCHK(c, hipMemcpy(c->xb_order, order.data(), buckets * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->xb_place, place.data(), buckets * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->xb_world = world;
+    c->xb_rank = rank;
+    c->xb_buckets = buckets;
+    c->xb_capacity = recv_capacity;
+    return NKML_OK;
+}
+
+int nkml_xb_front(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, uint32_t n_reads, uint64_t n_bases, uint16_t *d_send_keys,
+                  uint32_t *d_send_counts, uint64_t *send_totals, uint64_t *n_home)
+{
+    if (!c || (n_reads && (!d_seq || !d_offsets)) || !d_send_keys || !d_send_counts || !send_totals) return NKML_E_ARG;
+    if (!c->xb_order) return fail(c, NKML_E_STATE, "nkml_xb_enable first");
+    if (c->broken) return broken_context(c);
+    int rc = check_batch(c, n_reads, n_bases);
+    if (rc != NKML_OK) return rc;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint32_t W = c->xb_world, B = c->xb_buckets;
+    for (uint32_t r = 0; r < W; r++) send_totals[r] = 0;
+    if (n_home) *n_home = 0;
+    c->xb_n = 0;
+    if (n_reads == 0) {
+        HIPCHK(c, hipMemsetAsync(d_send_counts, 0, (uint64_t)B * sizeof(uint32_t), c->stream));
+        return NKML_OK;
+    }
+    const uint64_t n = (n_bases + 15) / 16 * 16;
+    if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu positions exceed the context's batch size", (unsigned long long)n);
+    if ((rc = run_prepare(c, d_seq, d_offsets, n_reads, n_bases)) != NKML_OK) return rc;
+    const uint64_t ta = (n + PT_TILE - 1) / PT_TILE, tb = ta + 256 + 1;
+    HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
+    if ((rc = pt_forward(c, nullptr, n, n_bases, false)) != NKML_OK) return rc;
+    hipLaunchKernelGGL(k_pt_bucket_bounds, B / 256 + 1, 256, 0, c->stream, c->pt_scanB, c->pt_pad, B, c->pt_bounds);
+    HIPCHK(c, hipMemsetAsync(c->xb_kept + B, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_xb_mark, B, 64, 0, c->stream, c->pt_keysB, c->pt_bounds, c->sat_bits, c->xb_place, c->xb_kept);
+    HIPCHK(c, hipGetLastError());
+    size_t tmp = c->xb_scan_tmp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->xb_scan_tmp, tmp, c->xb_kept, c->xb_base, 0u, (size_t)B + 1, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(k_xb_pack<true>, B, 64, 0, c->stream, c->pt_keysB, c->pt_bounds, c->pt_flagsB, c->sat_bits, c->xb_place, c->xb_base, d_send_keys, (const uint8_t *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(d_send_counts, c->xb_kept, (uint64_t)B * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    // every owner's total = differences of the scan at the first places of the ranks (through pinned memory)
+    if (W + 2 > 70) return fail(c, NKML_E_ARG, "more ranks than the staging area of the totals holds");
+    for (uint32_t r = 0; r <= W; r++)
+        HIPCHK(c, hipMemcpyAsync(&c->h_route_starts[r], c->xb_base + xb_first(B, W, r), sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_route_starts[W + 1], c->pt_bounds + B, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); // k-mers of the batch
+    if ((rc = fetch_counters(c)) != NKML_OK) return rc; // waits for the stream: the totals and the tallies are final
+    for (uint32_t r = 0; r < W; r++) send_totals[r] = c->h_route_starts[r + 1] - c->h_route_starts[r];
+    const uint64_t home = c->h_route_starts[W + 1] - (c->h_route_starts[W] - c->h_route_starts[0]); // what did not travel stayed home
+    c->route_home_total += home;
+    if (n_home) *n_home = home;
+    c->xb_n = n;
+    return check_bad_bases(c);
+}
+
+int nkml_xb_count(nkml_ctx *c, const uint16_t *d_recv_keys, const uint32_t *d_recv_counts, uint64_t n_recv, uint8_t *d_recv_flags)
+{
+    if (!c || !d_recv_counts || (n_recv && (!d_recv_keys || !d_recv_flags))) return NKML_E_ARG;
+    if (!c->xb_order) return fail(c, NKML_E_STATE, "nkml_xb_enable first");
+    if (c->broken) return broken_context(c);
+    if (n_recv > c->xb_capacity) return fail(c, NKML_E_ARG, "%llu keys arrived, the context was sized for %llu", (unsigned long long)n_recv, (unsigned long long)c->xb_capacity);
+    if (n_recv == 0) return NKML_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint32_t W = c->xb_world, B = c->xb_buckets, first = xb_first(B, W, c->xb_rank), mine = xb_first(B, W, c->xb_rank + 1) - first;
+    HIPCHK(c, hipMemsetAsync(c->xb_sizes, 0, ((uint64_t)B + 1) * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_xb_sizes, blocks_for(mine), 256, 0, c->stream, d_recv_counts, W, mine, c->xb_order, first, c->xb_sizes);
+    HIPCHK(c, hipGetLastError());
+    size_t tmp = c->xb_scan_tmp_bytes;
+    HIPCHK(c, rocprim::exclusive_scan(c->xb_scan_tmp, tmp, c->xb_sizes, c->xb_bounds2, 0u, (size_t)B + 1, rocprim::plus<uint32_t>(), c->stream));
+    tmp = c->xb_scan_tmp_bytes; // (the last input entry of an exclusive scan does not reach the output: reading one past the counts is harmless only
+    // if it is readable - the caller's array has world x mine entries, so the scan stops there and the runs' ends follow from the counts)
+    HIPCHK(c, rocprim::exclusive_scan(c->xb_scan_tmp, tmp, d_recv_counts, c->xb_run_at, 0u, (size_t)W * mine, rocprim::plus<uint32_t>(), c->stream));
+    hipLaunchKernelGGL(k_xb_merge<true>, mine * W, 64, 0, c->stream, d_recv_keys, (uint8_t *)nullptr, d_recv_counts, c->xb_run_at, W, mine, c->xb_order, first, c->xb_bounds2,
+                       c->xb_keys2, (const uint8_t *)nullptr);
+    HIPCHK(c, hipGetLastError());
+    int rc = pt_count_buckets(c, c->xb_keys2, c->xb_bounds2, c->xb_flags2, false, false);
+    if (rc != NKML_OK) return rc;
+    hipLaunchKernelGGL(k_xb_merge<false>, mine * W, 64, 0, c->stream, (const uint16_t *)nullptr, d_recv_flags, d_recv_counts, c->xb_run_at, W, mine, c->xb_order, first,
+                       c->xb_bounds2, (uint16_t *)nullptr, c->xb_flags2);
+    HIPCHK(c, hipGetLastError());
+    return NKML_OK;
+}
+
+int nkml_xb_finish(nkml_ctx *c, const uint8_t *d_back_flags, const uint64_t *d_offsets, uint32_t n_reads, int32_t *d_high, int32_t *d_total)
+{
+    if (!c || (n_reads && (!d_offsets || !d_high || !d_total))) return NKML_E_ARG;
+    if (!c->xb_order) return fail(c, NKML_E_STATE, "nkml_xb_enable first");
+    if (n_reads == 0) return NKML_OK;
+    if (c->xb_n == 0) return fail(c, NKML_E_STATE, "nkml_xb_finish without a batch from nkml_xb_front");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint32_t B = c->xb_buckets;
+    hipLaunchKernelGGL(k_xb_pack<false>, B, 64, 0, c->stream, c->pt_keysB, c->pt_bounds, c->pt_flagsB, (const uint32_t *)nullptr, c->xb_place, c->xb_base, (uint16_t *)nullptr, d_back_flags);
+    HIPCHK(c, hipGetLastError());
+    int rc = pt_backward(c, c->xb_n, nullptr);
+    if (rc != NKML_OK) return rc;
+    c->xb_n = 0;
+    return run_reduce_words(c, d_offsets, n_reads, d_high, d_total);
 }
 
 static int dump_table_into(nkml_ctx *c, unsigned long long *d_codes, uint32_t *d_cnts, unsigned long long *d_n, uint64_t *codes,

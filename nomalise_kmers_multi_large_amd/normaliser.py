@@ -210,6 +210,44 @@ class KmerNormaliser:
     def unroute_flags_device(self, d_recv_flags, d_send_src, n_sent, d_flags, n_keys):
         self._chk(self.lib.nkml_unroute_flags_device(self.h, d_recv_flags, d_send_src, n_sent, d_flags, n_keys))
 
+    def route_reads_ranked(self, d_seq, d_offsets, n_reads, n_bases, n_shards, d_send_keys, d_meta, d_tile_off):
+        """nkml_route_reads_ranked: (keys sent to every shard, positions the saturation bitmap answered here)"""
+        counts = (ctypes.c_uint64 * n_shards)()
+        home = ctypes.c_uint64(0)
+        self._chk(self.lib.nkml_route_reads_ranked(self.h, d_seq, d_offsets, n_reads, n_bases, n_shards, d_send_keys, d_meta, d_tile_off, counts,
+                                                   ctypes.byref(home)))
+        return [int(x) for x in counts], int(home.value)
+
+    def unroute_ranked(self, d_back_flags, d_meta, d_tile_off, n_positions, d_flags):
+        self._chk(self.lib.nkml_unroute_ranked(self.h, d_back_flags, d_meta, d_tile_off, n_positions, d_flags))
+
+    def sat_enable(self):
+        self._chk(self.lib.nkml_sat_enable(self.h))
+
+    def sat_collect(self, d_codes, max_codes):
+        n = ctypes.c_uint64(0)
+        self._chk(self.lib.nkml_sat_collect(self.h, d_codes, max_codes, ctypes.byref(n)))
+        return int(n.value)
+
+    def sat_apply(self, d_codes, n_codes):
+        self._chk(self.lib.nkml_sat_apply(self.h, d_codes, n_codes))
+
+    def xb_enable(self, world, rank, recv_capacity):
+        self._chk(self.lib.nkml_xb_enable(self.h, world, rank, recv_capacity))
+
+    def xb_front(self, d_seq, d_offsets, n_reads, n_bases, d_send_keys, d_send_counts, world):
+        """nkml_xb_front: (keys for every owner, positions answered here)"""
+        totals = (ctypes.c_uint64 * world)()
+        home = ctypes.c_uint64(0)
+        self._chk(self.lib.nkml_xb_front(self.h, d_seq, d_offsets, n_reads, n_bases, d_send_keys, d_send_counts, totals, ctypes.byref(home)))
+        return [int(x) for x in totals], int(home.value)
+
+    def xb_count(self, d_recv_keys, d_recv_counts, n_recv, d_recv_flags):
+        self._chk(self.lib.nkml_xb_count(self.h, d_recv_keys, d_recv_counts, n_recv, d_recv_flags))
+
+    def xb_finish(self, d_back_flags, d_offsets, n_reads, d_high, d_total):
+        self._chk(self.lib.nkml_xb_finish(self.h, d_back_flags, d_offsets, n_reads, d_high, d_total))
+
     def dump_table(self, max_entries=1 << 24):
         codes = np.zeros(max_entries, dtype=np.uint64)
         counts = np.zeros(max_entries, dtype=np.uint32)

@@ -282,21 +282,36 @@ class ReplicatedReadsNormaliser:
 
 def make_multi_gpu_normaliser(ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False,
                               stage_through_host=False, mode=None, group=None, root_only=False, time_phases=False):
-    """The multi-GPU normaliser that suits the job: replicated reads on up to four GPUs when a step fits one context
-    (measured per-rank compute of a 2 M-pair step at k=15: 10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs, plus one all-gather
-    of packed reads, hidden behind the counting, and one sum of counters; the key exchange would put 0.5-1.5 GB per
-    step and rank on the links - all of it on one link with two GPUs - and is expected level with it on four only if
-    the all-to-all reaches most of the links' rate), the key exchange of `sharded.py` otherwise.  `mode` or the environment variable NKML_MULTI_GPU ("replicated" / "exchange")
-    overrides the choice.  Returns (normaliser, engine, mode)."""
+    """The multi-GPU normaliser that suits the job.  Three modes:
+      "replicated": packed reads all-gathered, every GPU extracts and counts its shard of the k-mers (this file); per-rank
+                    compute of a 2 M-pair step at k=15 measured at 10.5 / 13.3 / 15.9 ms on 2 / 3 / 4 GPUs: chosen for two;
+      "bucketed":   every GPU partitions its own k-mers by bucket, unsaturated ones travel to the bucket's owner as 16-bit
+                    codes (bucketed.py; k <= 15, depth <= 16383): about 6 ms of compute per rank and 2 M-pair step whatever
+                    the number of GPUs, 0.3-0.7 GB per rank and step on the links: chosen from three GPUs on (by estimate
+                    for three and four: no such node was at hand);
+      "exchange":   k-mers routed by a hash of the k-mer and counted at the owner with the full pipeline (sharded.py): every k.
+    `mode` or the environment variable NKML_MULTI_GPU overrides the choice.  Returns (normaliser, engine, mode)."""
     import os
     from .sharded import HipShardEngine, ShardedNormaliser
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    mode = mode or os.environ.get("NKML_MULTI_GPU") or ("replicated" if world <= 4 and fits(ksize, depth, world, max_bases) else "exchange")
+    can_bucket = ksize <= 15 and 2 <= depth <= 16383 and ((1 << (2 * ksize)) >> 14) >= world
+    if not (mode or os.environ.get("NKML_MULTI_GPU")):
+        if world <= 2 and fits(ksize, depth, world, max_bases):
+            mode = "replicated"
+        elif can_bucket:
+            mode = "bucketed"
+        else:
+            mode = "replicated" if world <= 4 and fits(ksize, depth, world, max_bases) else "exchange"
+    mode = mode or os.environ.get("NKML_MULTI_GPU")
     if mode == "replicated":
         engine = HipReplicaEngine(ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=profile)
         return ReplicatedReadsNormaliser(engine, group=group, stage_through_host=stage_through_host, root_only=root_only,
                                          time_phases=time_phases), engine, mode
+    if mode == "bucketed":
+        from .bucketed import BucketedNormaliser, HipBucketEngine
+        engine = HipBucketEngine(ksize, depth, coverage, canonical, device, max_reads, max_bases, world, rank, profile=profile)
+        return BucketedNormaliser(engine, group=group, stage_through_host=stage_through_host, time_phases=time_phases), engine, mode
     if mode != "exchange":
-        raise ValueError("NKML_MULTI_GPU must be 'replicated' or 'exchange', not %r" % mode)
-    engine = HipShardEngine(ksize, depth, coverage, canonical, device, max_reads=max_reads, max_bases=max_bases, profile=profile)
+        raise ValueError("NKML_MULTI_GPU must be 'replicated', 'bucketed' or 'exchange', not %r" % mode)
+    engine = HipShardEngine(ksize, depth, coverage, canonical, device, max_reads=max_reads, max_bases=max_bases, profile=profile, world=world)
     return ShardedNormaliser(engine, group=group, stage_through_host=stage_through_host, time_phases=time_phases), engine, mode

@@ -15,6 +15,13 @@ is sharded by k-mer instead and results stay identical to the single-stream run:
   5. per-read counters are reduced where the reads live and gathered on rank 0, which takes the keep/skip
      decisions for the whole step (ordered write-back happens there)
 
+Saturated k-mers stay home (engines that offer sat_collect / sat_apply; the HIP engine does at k <= 15): once a k-mer's
+count at its owner has reached depth - 1, every later occurrence is "high" whatever the owner would add, so it need not
+travel.  Every rank keeps a bitmap of k-mers known to be that far; routing answers their occurrences on the spot.  After
+counting a step, every owner lists the k-mers that got there in it and the lists go round in one all-gather.  A bitmap
+may lag (with look-ahead the next step is routed before this one is counted): a k-mer without its bit travels and is
+counted as before, so results do not depend on when a bit arrives.
+
 The engine object does the device work; `HipShardEngine` is the product one.  Tests drive the same exchange
 logic over gloo with a CPU checker engine.
 """
@@ -28,7 +35,14 @@ from .phases import Phases
 class HipShardEngine:
     """Stage-by-stage face of the HIP library on one GPU, holding torch tensors for the buffers."""
 
-    def __init__(self, ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False, slack=1.5):
+    MAX_NEW_SATURATED = 1 << 23   # k-mers one step can announce as newly saturated (the rest is announced never: see sat_collect)
+
+    def __init__(self, ksize, depth, coverage, canonical, device, max_reads, max_bases, profile=False, slack=1.5, world=1,
+                 ranked=None, stay_home=None):
+        """ranked: route with 16 bits per base position instead of 4 bytes per sent key (None = wherever the world has at most
+        32 ranks); stay_home: keep the saturation bitmap (None = wherever the table allows: k <= 15 on the partitioned
+        direct table); the environment variables NKML_EXCHANGE_RANKED / NKML_EXCHANGE_STAY_HOME = 0 / 1 override both."""
+        import os
         from .normaliser import KmerNormaliser
         self.dev = torch.device("cuda", device)
         self.cap = int(max_bases * slack) // 16 * 16 + 64
@@ -38,26 +52,58 @@ class HipShardEngine:
         self.key_dtype = torch.int32 if self.nk.key_bytes == 4 else torch.int64
         npos = (max_bases + 15) // 16 * 16
         self.max_positions = npos
-        self.keys = torch.zeros(npos, dtype=self.key_dtype, device=self.dev)
+        env = os.environ.get("NKML_EXCHANGE_RANKED")
+        self.ranked = (world <= 32) if ranked is None else bool(ranked)
+        if env in ("0", "1"):
+            self.ranked = env == "1"
+        env = os.environ.get("NKML_EXCHANGE_STAY_HOME")
+        want_home = self.ranked if stay_home is None else bool(stay_home)
+        if env in ("0", "1"):
+            want_home = env == "1"
+        self.stay_home = False
+        if want_home and self.ranked and ksize <= 15 and self.nk.stats()["partitioned"]:
+            self.nk.sat_enable()
+            self.stay_home = True
+            self.sat_codes = torch.zeros(self.MAX_NEW_SATURATED, dtype=torch.int32, device=self.dev)
+        self.home_positions = self.home_total = 0   # base positions the bitmap answered: in the last step routed / since the start
+        self._keys = None   # key array of the stage-by-stage form (kmerise + route), made when first asked for
         # two sets of what the key exchange touches: the next step's keys travel while this step's are counted
         self.send_keys2 = [torch.zeros(npos, dtype=self.key_dtype, device=self.dev) for _ in range(2)]
-        self.send_src2 = [torch.zeros(npos, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        if self.ranked:   # per base position: shard and rank in the routing tile; per routing tile and shard: where its run starts
+            tiles = (npos + 1023) // 1024
+            self.send_src2 = [(torch.zeros(tiles * 1024, dtype=torch.int16, device=self.dev), torch.zeros(tiles * world + 1, dtype=torch.int32, device=self.dev))
+                              for _ in range(2)]
+        else:
+            self.send_src2 = [torch.zeros(npos, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self._plain_src = None   # source positions of the stage-by-stage route() when the exchange itself runs ranked
         self.recv_keys2 = [torch.zeros(self.cap, dtype=self.key_dtype, device=self.dev) for _ in range(2)]
         self.send_keys, self.send_src, self.recv_keys = self.send_keys2[0], self.send_src2[0], self.recv_keys2[0]
+        self.world = world
         self.flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
         self.recv_flags = torch.zeros(self.cap, dtype=torch.uint8, device=self.dev)
         self.back_flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
         self.high = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
         self.total = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
 
+    @property
+    def keys(self):
+        if self._keys is None:
+            self._keys = torch.zeros(self.max_positions, dtype=self.key_dtype, device=self.dev)
+        return self._keys
+
     def kmerise(self, seq, offsets, n_reads, n_bases):
         self.nk.kmerise_device(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, self.keys.data_ptr())
         return self.keys[: (n_bases + 15) // 16 * 16]
 
     def route(self, keys, n_shards):
-        counts = self.nk.route_keys_device(keys.data_ptr(), keys.numel(), n_shards, self.send_keys.data_ptr(), self.send_src.data_ptr())
+        src = self.send_src
+        if self.ranked:   # the stage-by-stage form always works with source positions
+            if self._plain_src is None:
+                self._plain_src = torch.zeros(self.max_positions, dtype=torch.int32, device=self.dev)
+            src = self._plain_src
+        counts = self.nk.route_keys_device(keys.data_ptr(), keys.numel(), n_shards, self.send_keys.data_ptr(), src.data_ptr())
         n = sum(counts)
-        return self.send_keys[:n], self.send_src[:n], counts
+        return self.send_keys[:n], src[:n], counts
 
     def use_buffers(self, which):
         """Which of the two sets of exchange buffers kmerise_route / route / recv_buffer hand out from now on."""
@@ -66,6 +112,17 @@ class HipShardEngine:
     def kmerise_route(self, seq, offsets, n_reads, n_bases, n_shards):
         """kmerise + route in one go: the k-mers are recomputed from the packed reads by the routing passes
         themselves, no key array is written.  Returns (send_keys, send_src, counts, n_positions)."""
+        if self.ranked:
+            if n_shards != self.world:
+                raise RuntimeError("the engine was sized for %d ranks, not %d" % (self.world, n_shards))
+            if n_reads == 0:
+                return self.send_keys[:0], self.send_src, [0] * n_shards, 0
+            meta, tile_off = self.send_src
+            counts, home = self.nk.route_reads_ranked(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, n_shards,
+                                                      self.send_keys.data_ptr(), meta.data_ptr(), tile_off.data_ptr())
+            self.home_positions = home          # of this step
+            self.home_total += home
+            return self.send_keys[:sum(counts)], self.send_src, counts, (n_bases + 15) // 16 * 16
         if n_reads == 0:   # a rank may have nothing to bring to a step
             return self.send_keys[:0], self.send_src[:0], [0] * n_shards, 0
         counts = self.nk.route_reads_device(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, n_shards,
@@ -93,13 +150,29 @@ class HipShardEngine:
         return self.back_flags[:n]
 
     def unroute(self, back_flags, send_src, n_positions):
+        if isinstance(send_src, tuple):
+            meta, tile_off = send_src
+            self.nk.unroute_ranked(back_flags.data_ptr(), meta.data_ptr(), tile_off.data_ptr(), n_positions, self.flags.data_ptr())
+            return self.flags[:n_positions]
         self.nk.unroute_flags_device(back_flags.data_ptr(), send_src.data_ptr(), back_flags.numel(), self.flags.data_ptr(), n_positions)
         return self.flags[:n_positions]
+
+    def sat_collect(self):
+        """k-mers of this rank's table that reached depth - 1 since the last call (device tensor of codes); None if this
+        engine keeps no saturation bitmap.  Waits for the device."""
+        if not self.stay_home:
+            return None
+        n = self.nk.sat_collect(self.sat_codes.data_ptr(), self.sat_codes.numel())
+        return self.sat_codes[:n]
+
+    def sat_apply(self, codes):
+        if self.stay_home and codes.numel():
+            self.nk.sat_apply(codes.data_ptr(), codes.numel())
 
     def reduce(self, flags, offsets, n_reads):
         if n_reads == 0:
             return self.high[:0], self.total[:0]
-        self.nk.reduce_reads_device(self.keys.data_ptr(), flags.data_ptr(), offsets.data_ptr(), n_reads, self.high.data_ptr(), self.total.data_ptr())
+        self.nk.reduce_reads_device(flags.data_ptr(), flags.data_ptr(), offsets.data_ptr(), n_reads, self.high.data_ptr(), self.total.data_ptr())
         return self.high[:n_reads], self.total[:n_reads]
 
     def decide(self, high, total, n_units, paired, keep):
@@ -110,6 +183,7 @@ class HipShardEngine:
 
     def reset(self):
         self.nk.reset()
+        self.home_positions = self.home_total = 0
 
     def stats(self):
         return self.nk.stats()
@@ -255,6 +329,44 @@ class ShardedNormaliser:
                 raise err
             raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or a batch beyond the sizes it was set up for)")
 
+    def _agree_and_share_saturated(self, err, like):
+        """_agree after the counting stage, and with an engine that keeps a saturation bitmap: every rank's newly saturated
+        k-mers reach every other rank (the sizes ride in the same small collective that carries the error flags; the lists
+        follow in one all-gather, padded to the longest)."""
+        eng, W = self.eng, self.world
+        collect = getattr(eng, "sat_collect", None)
+        new = None
+        if collect is not None and err is None:
+            try:
+                new = collect()
+            except Exception as e:
+                err = e
+        if collect is None or (new is None and err is None):
+            return self._agree(err, like)
+        cdev = "cpu" if self.stage_through_host or not like.is_cuda else like.device
+        mine = torch.tensor([0 if err is None else 1, 0 if new is None else int(new.numel())], dtype=torch.int64, device=cdev)
+        table = torch.empty(2 * W, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(table, mine, group=self.group)
+        rows = table.view(W, 2).tolist()
+        if any(r[0] for r in rows):
+            if err is not None:
+                raise err
+            raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or a batch beyond the sizes it was set up for)")
+        longest = max(r[1] for r in rows)
+        self.phases.add_bytes("newly saturated k-mers announced", int(new.numel()) * new.element_size() * (W - 1))
+        if W == 1 or longest == 0:
+            return
+        host = self.stage_through_host and new.is_cuda
+        pad = torch.zeros(longest, dtype=new.dtype, device="cpu" if host else new.device)
+        pad[: new.numel()].copy_(new)
+        everyone = torch.empty(W * longest, dtype=new.dtype, device=pad.device)
+        dist.all_gather_into_tensor(everyone, pad, group=self.group)
+        if host:
+            everyone = everyone.to(new.device)
+        for p in range(W):
+            if p != self.rank and rows[p][1]:
+                eng.sat_apply(everyone[p * longest: p * longest + int(rows[p][1])])
+
     def _start_exchange(self, seq, offsets, n_reads, n_bases):
         """Everything of a step that does not need the table: k-mers, routing, the all-to-all of keys (left in flight)."""
         eng, W = self.eng, self.world
@@ -319,7 +431,7 @@ class ShardedNormaliser:
         except Exception as e:   # e.g. the table shard cannot grow any further
             err = e
         with ph.host("agree (host round trip)"):
-            self._agree(err, seq)
+            self._agree_and_share_saturated(err, seq)
         if W == 1 and hasattr(eng, "kmerise_route"):
             back = recv_flags
         else:

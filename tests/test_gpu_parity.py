@@ -496,6 +496,7 @@ def test_sharded_normaliser_over_rccl_world_of_one(nk):
                 np.testing.assert_array_equal(total.cpu().numpy(), t[:nr].cpu().numpy())
                 np.testing.assert_array_equal(gathered[0][0].cpu().numpy(), h[:nr].cpu().numpy())
             assert int(h.sum()) > 0 and eng.stats()["unique_kmers"] == g.unique_kmers
+            assert eng.ranked and eng.stay_home and eng.stats()["kmers_counted"] == g.stats()["kmers_counted"]
     finally:
         dist.destroy_process_group()
 
@@ -553,7 +554,7 @@ def test_known_answer_two_million_synthetic_pairs(nk, k, canonical, batch_pairs,
         assert g.unique_kmers == want_unique
 
 
-def _two_rank_worker(rank, world, port, steps, bp, q):
+def _two_rank_worker(rank, world, port, steps, bp, q, ranked=None, stay_home=None):
     import torch
     import torch.distributed as dist
     from nomalise_kmers_multi_large_amd import synth
@@ -562,7 +563,8 @@ def _two_rank_worker(rank, world, port, steps, bp, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, slack=2.0)
+        eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, slack=2.0, world=world, ranked=ranked, stay_home=stay_home)
+        assert eng.ranked == (ranked is not False) and eng.stay_home == (ranked is not False and stay_home is not False)
         sn = ShardedNormaliser(eng, stage_through_host=True, max_message_bytes=4 << 20)
         blocks = list(synth.pair_blocks(steps * bp, seed=11 + rank, transcripts=30, block=bp))
         out, batches = [], []
@@ -574,31 +576,36 @@ def _two_rank_worker(rank, world, port, steps, bp, q):
             sn.synchronize()
             if rank == 0:
                 out.append([g.cpu().numpy().copy() for g in gathered])
+        st = eng.stats()
+        tallies = torch.tensor([st["kmers_counted"], st["kmers_saturated"], st["unique_kmers"], eng.home_total], dtype=torch.int64)
+        dist.all_reduce(tallies)
         if rank == 0:
-            q.put(out)
+            q.put((out, tallies.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu_equal_single_table(nk):
-    """Two ranks with the product engine (each its own context and table shard on this GPU), exchanging over gloo
+@pytest.mark.parametrize("world,ranked,stay_home", [(2, False, False), (2, True, False), (2, True, True), (3, True, True)])
+def test_two_ranks_share_one_gpu_equal_single_table(nk, world, ranked, stay_home):
+    """Two (three) ranks with the product engine (each its own context and table shard on this GPU), exchanging over gloo
     through host memory: the per-read counters gathered on rank 0 equal those of one table reading the global
-    stream (per step: rank 0's reads, then rank 1's)."""
+    stream (per step: rank 0's reads, then rank 1's, ...).  With source positions per sent key, with ranked routing, and with
+    saturated k-mers staying home (then fewer occurrences reach a table than were read, and the statistics still add up)."""
     import socket
     import torch
     import torch.multiprocessing as mp
     from nomalise_kmers_multi_large_amd import synth
-    world, steps, bp = 2, 3, 15000
+    steps, bp = 3, 15000
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, steps, bp, q)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, steps, bp, q, ranked, stay_home)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    got, tallies = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -618,6 +625,93 @@ def test_two_ranks_share_one_gpu_equal_single_table(nk):
                 np.testing.assert_array_equal(got[step][r][1], t[:nr].cpu().numpy())
                 crossed += int(h[:nr].sum())
         assert crossed > 0
+        st = g.stats()
+        # summed over the ranks: every occurrence read is accounted for, whether it reached a table or stayed home
+        # (the "saturated" tally depends on where the batches are cut - an occurrence counts if its k-mer was at depth - 1 when
+        # its batch began, and a step here is one batch of all ranks' reads - so it is only close to the single table's)
+        assert tallies[0] == st["kmers_counted"] and tallies[2] == st["unique_kmers"]
+        assert 0 < tallies[1] <= st["kmers_saturated"] and tallies[1] > 0.99 * st["kmers_saturated"]
+        # with the bitmap a good part of the saturated occurrences never left the rank that read them
+        assert (tallies[3] > 0.3 * st["kmers_saturated"]) if (ranked and stay_home) else (tallies[3] == 0)
+
+
+def _bucket_rank_worker(rank, world, port, steps, bp, k, depth, stay_home, q):
+    import torch
+    import torch.distributed as dist
+    from nomalise_kmers_multi_large_amd import synth
+    from nomalise_kmers_multi_large_amd.bucketed import BucketedNormaliser, HipBucketEngine
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        eng = HipBucketEngine(k, depth, 0.9, False, 0, 2 * bp, 2 * bp * 150, world, rank, slack=2.0, stay_home=stay_home)
+        sn = BucketedNormaliser(eng, stage_through_host=True, max_message_bytes=1 << 20)
+        out = []
+        for step, (c1, c2) in enumerate(synth.pair_blocks(steps * bp, seed=11 + rank, transcripts=30, block=bp)):
+            if rank == world - 1 and step == 1:   # the last rank brings nothing to the second step
+                seq, off = np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
+            else:
+                seq, off = synth.interleave(c1, c2)
+            high, total, gathered = sn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq))
+            sn.synchronize()
+            if rank == 0:
+                out.append([g.cpu().numpy().copy() for g in gathered])
+        st = eng.stats()
+        tallies = torch.tensor([st["kmers_counted"], st["unique_kmers"], eng.home_total], dtype=torch.int64)
+        dist.all_reduce(tallies)
+        if rank == 0:
+            q.put((out, tallies.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,depth,stay_home", [(2, 15, 100, True), (3, 15, 100, True), (2, 15, 200, False), (3, 13, 20, True), (4, 14, 100, True)])
+def test_bucket_ordered_exchange_ranks_share_one_gpu_equal_single_table(nk, world, k, depth, stay_home):
+    """The bucket-ordered exchange with the product engine: two to four ranks (each its own context and its share of the table's
+    buckets on this GPU) exchanging over gloo through host memory.  The per-read counters gathered on rank 0 equal those of
+    one table reading the global stream (per step: rank 0's reads, then rank 1's, ...); one rank brings nothing to one step;
+    with the saturation bitmap a good part of the occurrences never leaves the rank that read them, and every occurrence
+    is still accounted for.  One-byte and two-byte table entries, several key-space sizes."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    from nomalise_kmers_multi_large_amd import synth
+    steps, bp = 3, 12000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_rank_worker, args=(r, world, port, steps, bp, k, depth, stay_home, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, tallies = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    data = [list(synth.pair_blocks(steps * bp, seed=11 + r, transcripts=30, block=bp)) for r in range(world)]
+    with nk.KmerNormaliser(k, depth, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
+        h = torch.zeros(2 * bp, dtype=torch.int32, device="cuda")
+        t = torch.zeros_like(h)
+        crossed = 0
+        for step in range(steps):
+            for r in range(world):
+                if r == world - 1 and step == 1:
+                    assert got[step][r].shape[1] == 0
+                    continue
+                seq, off = synth.interleave(*data[r][step])
+                d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+                nr = len(off) - 1
+                g.process_device(d_seq.data_ptr(), d_off.data_ptr(), nr, len(seq), h.data_ptr(), t.data_ptr())
+                g.synchronize()
+                np.testing.assert_array_equal(got[step][r][0], h[:nr].cpu().numpy())
+                np.testing.assert_array_equal(got[step][r][1], t[:nr].cpu().numpy())
+                crossed += int(h[:nr].sum())
+        assert crossed > 0
+        st = g.stats()
+        assert tallies[0] == st["kmers_counted"] and tallies[1] == st["unique_kmers"]
+        assert (tallies[2] > 0.3 * st["kmers_saturated"]) if stay_home else (tallies[2] == 0)
 
 
 @pytest.mark.parametrize("k", [14, 15])
@@ -857,9 +951,9 @@ def test_one_batch_of_more_than_two_to_the_31_positions(nk, k):
         small.close()
 
 
-@pytest.mark.parametrize("mode", ["replicated", "exchange"])
+@pytest.mark.parametrize("mode", ["replicated", "exchange", "bucketed"])
 def test_multi_gpu_step_to_which_a_rank_brings_nothing(nk, mode):
-    """Both multi-GPU normalisers over RCCL (world of one): a step without any read between two ordinary steps returns
+    """The multi-GPU normalisers over RCCL (world of one): a step without any read between two ordinary steps returns
     empty counters and leaves the table alone; the ordinary steps equal the single-table path."""
     import socket
     import torch

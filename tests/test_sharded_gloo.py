@@ -23,9 +23,14 @@ def owner_np(keys, n_shards):
 class CheckerEngine:
     """Same stage interface as HipShardEngine, on CPU tensors, with the oracle as the table."""
 
-    def __init__(self, k, depth, canonical):
-        self.k, self.canonical = k, canonical
+    def __init__(self, k, depth, canonical, stay_home=False):
+        self.k, self.canonical, self.depth = k, canonical, depth
         self.o = Oracle(k, depth, canonical)
+        # stay_home: the protocol of the saturation bitmap (sat_collect / sat_apply), with Python sets for the bitmap
+        self.stay_home = stay_home
+        self.sat, self.seen, self.home_positions = set(), set(), 0
+        if not stay_home:
+            self.sat_collect = None   # ShardedNormaliser asks with getattr(engine, "sat_collect", None)
 
     def kmerise(self, seq, offsets, n_reads, n_bases):
         keys = Oracle.keys(self.k, self.canonical, seq.numpy(), offsets.numpy().astype(np.uint64))
@@ -34,22 +39,43 @@ class CheckerEngine:
     def route(self, keys, n_shards):
         k = keys.numpy().view(np.uint64)
         nz = np.nonzero(k)[0]
+        home = np.zeros(0, dtype=np.int64)
+        if self.stay_home:   # k-mers known to be saturated are answered here
+            known = np.isin(k[nz], np.fromiter(self.sat, dtype=np.uint64, count=len(self.sat)))
+            home, nz = nz[known], nz[~known]
+            self.home_positions += len(home)
         own = owner_np(k[nz], n_shards).astype(np.int64)
         order = np.argsort(own, kind="stable")
         counts = [int((own == s).sum()) for s in range(n_shards)]
-        return torch.from_numpy(k[nz][order].view(np.int64).copy()), torch.from_numpy(nz[order].astype(np.int32)), counts
+        src = torch.from_numpy(nz[order].astype(np.int32))
+        return torch.from_numpy(k[nz][order].view(np.int64).copy()), ((src, torch.from_numpy(home)) if self.stay_home else src), counts
 
     def recv_buffer(self, n):
         return torch.empty(n, dtype=torch.int64)
 
     def count(self, recv_keys):
-        return torch.from_numpy(self.o.count_keys(recv_keys.numpy().view(np.uint64)))
+        keys = recv_keys.numpy().view(np.uint64)
+        self.seen.update(np.unique(keys).tolist())
+        return torch.from_numpy(self.o.count_keys(keys))
+
+    def sat_collect(self):
+        """k-mers of this shard whose count reached depth - 1 since the last call"""
+        new = [c for c in self.seen if c not in self.sat and self.o.count_of(c) >= self.depth - 1]
+        self.sat.update(new)
+        self.seen.clear()
+        return torch.tensor(new, dtype=torch.int64)
+
+    def sat_apply(self, codes):
+        self.sat.update(codes.numpy().view(np.uint64).tolist())
 
     def back_buffer(self, n):
         return torch.empty(n, dtype=torch.uint8)
 
     def unroute(self, back_flags, send_src, n_positions):
         flags = np.zeros(n_positions, dtype=np.uint8)
+        if isinstance(send_src, tuple):
+            send_src, home = send_src
+            flags[home.numpy()] = 1   # "high"
         flags[send_src.numpy()] = back_flags.numpy()
         return torch.from_numpy(flags)
 
@@ -79,14 +105,14 @@ def concat(reads):
     return np.frombuffer(b"".join(reads), dtype=np.uint8).copy(), off
 
 
-def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=256 << 20, ahead=False):
+def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=256 << 20, ahead=False, stay_home=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.sharded import ShardedNormaliser
         # with small messages also run the start-up check of the exchange (3000 elements per peer, many rounds)
-        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical), max_message_bytes=max_message_bytes, check_elems=3000 if max_message_bytes < 4096 else 0)
+        sn = ShardedNormaliser(CheckerEngine(k, depth, canonical, stay_home), max_message_bytes=max_message_bytes, check_elems=3000 if max_message_bytes < 4096 else 0)
         assert sn.max_message_bytes == max_message_bytes
         out, batches = [], []
         for step in range(steps):
@@ -99,10 +125,10 @@ def worker(rank, world, port, k, depth, canonical, steps, q, max_message_bytes=2
             high, total, gathered = sn.process_step(*batches[step], then=then)
             if rank == 0:
                 out.append([g.numpy().copy() for g in gathered])
-        uniq = torch.tensor([sn.stats()["unique_kmers"]], dtype=torch.int64)
+        uniq = torch.tensor([sn.stats()["unique_kmers"], sn.eng.home_positions], dtype=torch.int64)
         dist.all_reduce(uniq)
         if rank == 0:
-            q.put((out, int(uniq.item())))
+            q.put((out, int(uniq[0].item()), int(uniq[1].item())))
     finally:
         dist.destroy_process_group()
 
@@ -117,18 +143,22 @@ def free_port():
 
 # the last case exchanges in rounds of at most 1000 bytes per message (several rounds per step)
 # and the last two send the next step's keys ahead of the current step's counting
-@pytest.mark.parametrize("world,k,depth,canonical,msg,ahead", [(2, 9, 3, False, 256 << 20, False), (2, 21, 2, True, 256 << 20, False),
-                                                               (3, 11, 4, True, 256 << 20, False), (2, 11, 3, True, 1000, False),
-                                                               (3, 11, 4, True, 256 << 20, True), (2, 11, 3, True, 1000, True)])
-def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg, ahead):
-    steps = 3
+# ... and the cases with stay_home keep saturated k-mers from travelling (bitmaps fed by the owners' lists after every step)
+@pytest.mark.parametrize("world,k,depth,canonical,msg,ahead,stay_home", [
+    (2, 9, 3, False, 256 << 20, False, False), (2, 21, 2, True, 256 << 20, False, False),
+    (3, 11, 4, True, 256 << 20, False, False), (2, 11, 3, True, 1000, False, False),
+    (3, 11, 4, True, 256 << 20, True, False), (2, 11, 3, True, 1000, True, False),
+    (2, 7, 3, False, 256 << 20, False, True), (3, 7, 4, True, 256 << 20, True, True), (2, 9, 2, True, 1000, True, True)])
+def test_sharded_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg, ahead, stay_home):
+    steps = 4 if stay_home else 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg, ahead)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg, ahead, stay_home)) for r in range(world)]
     for p in procs:
         p.start()
-    got, uniq = q.get(timeout=120)
+    got, uniq, stayed = q.get(timeout=120)
+    assert (stayed > 0) == stay_home   # short k-mers over three letters repeat: some are saturated after the first step
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
