@@ -359,10 +359,11 @@ def main():
     total_pairs = n_pairs * world
     value = total_pairs / elapsed
     unique = st["unique_kmers"]
+    occ_all_ranks = st["kmers_counted"]
     if dist is not None:
-        u = torch.tensor([unique], dtype=torch.int64, device=cdev)
+        u = torch.tensor([unique, occ_all_ranks], dtype=torch.int64, device=cdev)
         dist.all_reduce(u)
-        unique = int(u.item())
+        unique, occ_all_ranks = int(u[0].item()), int(u[1].item())
 
     multi = None
     if dist is not None:
@@ -412,12 +413,20 @@ def main():
         else:
             kernel = "k_count_words_direct" if k <= 16 else "k_count_words_hashed"
             unit_ms = st["count_kernel_ms"] / launches
+        if multi is not None and multi_mode == "bucketed":
+            # bucket-ordered exchange: a rank's counting work of a step is spread over three device phases (partition + pack of
+            # its own reads, the bucket kernels over what it owns, the flags' way home); the unit is one rank's share of a step
+            dev_phases = ("partition + pack", "count", "flags home + per-read sums")
+            kernel = "bucket-ordered exchange, device phases of one rank and step (%s)" % ", ".join(dev_phases)
+            unit_ms = sum(multi["phase_ms_per_step"][n]["median"] for n in dev_phases if n in multi["phase_ms_per_step"])
+            launches = args.steps * world
+            occ = occ_all_ranks
         occ_per_launch = occ / launches
         alg_bytes_per_launch = 32.0 * occ_per_launch
         achieved = alg_bytes_per_launch / (unit_ms * 1e-3) / 1e9 if unit_ms > 0 else 0.0
         traffic = design = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_counting_stage.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and world == 1:   # (the records are of the single-GPU pipeline)
             try:
                 for rec in json.load(open(pmc_path)):
                     if rec.get("ksize") == k and rec.get("pairs_per_step") == pps and bool(rec.get("partitioned")) == partitioned \
@@ -461,7 +470,7 @@ def main():
                 "distinct_steps_of_data": data_steps, "ksize": k, "canonical": bool(canonical), "partitioned": bool(partitioned)},
             "unique_kmers": unique,
             "unique_kmers_per_s": unique / elapsed,
-            "kmer_occurrences_per_s": occ * world / elapsed,
+            "kmer_occurrences_per_s": occ_all_ranks / elapsed,
             "algorithmic_GBps_whole_path": value * algorithmic_bytes_per_pair(k) / 1e9,
             "roofline": dict({"bound": "hbm", "kernel": kernel, "achieved": achieved,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -479,7 +479,7 @@ def test_sharded_normaliser_over_rccl_world_of_one(nk):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         bp = 20000
-        eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150)
+        eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, stay_home=True)
         sn = ShardedNormaliser(eng, max_message_bytes=1 << 20)
         with nk.KmerNormaliser(15, 100, 0.9, max_batch_reads=2 * bp, max_batch_bases=2 * bp * 150) as g:
             h = torch.zeros(2 * bp, dtype=torch.int32, device="cuda")
@@ -564,7 +564,7 @@ def _two_rank_worker(rank, world, port, steps, bp, q, ranked=None, stay_home=Non
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         eng = HipShardEngine(15, 100, 0.9, False, 0, max_reads=2 * bp, max_bases=2 * bp * 150, slack=2.0, world=world, ranked=ranked, stay_home=stay_home)
-        assert eng.ranked == (ranked is not False) and eng.stay_home == (ranked is not False and stay_home is not False)
+        assert eng.ranked == (ranked is not False) and eng.stay_home == bool(ranked is not False and stay_home)
         sn = ShardedNormaliser(eng, stage_through_host=True, max_message_bytes=4 << 20)
         blocks = list(synth.pair_blocks(steps * bp, seed=11 + rank, transcripts=30, block=bp))
         out, batches = [], []
