@@ -32,7 +32,11 @@ def _as_bytes(t):
 
 
 class HipBucketEngine:
-    """Stage-by-stage face of the HIP library's bucket-ordered exchange on one GPU, holding torch tensors for the buffers."""
+    """Stage-by-stage face of the HIP library's bucket-ordered exchange on one GPU, holding torch tensors for the buffers.
+    Three library contexts: two that play the sender (pack, partition, compact; the way home) for alternate steps, so that a
+    step's k-mers can be partitioned and sent while the step before it is still being counted and brought home, and one that
+    owns this rank's buckets of the table.  (A sender never touches its context's table, the owner never its partition
+    buffers, which are created small.)"""
 
     MAX_NEW_SATURATED = 1 << 23
 
@@ -45,42 +49,59 @@ class HipBucketEngine:
         self.dev = torch.device("cuda", device)
         self.world, self.rank = world, rank
         self.cap = int(max_bases * slack) // 16 * 16 + 64   # keys this rank can receive in one step
-        self.nk = KmerNormaliser(ksize, depth, coverage, canonical, device=device, max_batch_reads=max_reads,
-                                 max_batch_bases=max_bases, profile=profile, flags=B.NKML_F_COUNT_PARTITIONED)
-        self.nk.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
-        self.buckets = max(1, (1 << (2 * ksize)) >> 14)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.senders = []
+        for _ in range(2):
+            nk = KmerNormaliser(ksize, depth, coverage, canonical, device=device, max_batch_reads=max_reads, max_batch_bases=max_bases,
+                                flags=B.NKML_F_COUNT_PARTITIONED)
+            nk.set_stream(stream)
+            nk.xb_enable(world, rank, 16)
+            self.senders.append(nk)
+        self.nk = KmerNormaliser(ksize, depth, coverage, canonical, device=device, max_batch_reads=16, max_batch_bases=4096,
+                                 profile=profile, flags=B.NKML_F_COUNT_PARTITIONED)
+        self.nk.set_stream(stream)
         self.nk.xb_enable(world, rank, self.cap)
+        self.buckets = max(1, (1 << (2 * ksize)) >> 14)
         env = os.environ.get("NKML_EXCHANGE_STAY_HOME")
         self.stay_home = bool(stay_home) if env not in ("0", "1") else env == "1"
         if self.stay_home:
-            self.nk.sat_enable()
+            for nk in self.senders + [self.nk]:
+                nk.sat_enable()
             self.sat_codes = torch.zeros(self.MAX_NEW_SATURATED, dtype=torch.int32, device=self.dev)
         npos = (max_bases + 15) // 16 * 16
         self.max_positions = npos
         self.key_dtype = torch.int16
         self.mine = first_place(self.buckets, world, rank + 1) - first_place(self.buckets, world, rank)
-        self.send_keys = torch.zeros(npos, dtype=torch.int16, device=self.dev)
-        self.send_counts = torch.zeros(self.buckets, dtype=torch.int32, device=self.dev)
-        self.recv_keys = torch.zeros(self.cap, dtype=torch.int16, device=self.dev)
-        self.recv_counts = torch.zeros(world * self.mine, dtype=torch.int32, device=self.dev)
+        # two sets of what a step's exchange touches, one per sender
+        self.send_keys2 = [torch.zeros(npos, dtype=torch.int16, device=self.dev) for _ in range(2)]
+        self.send_counts2 = [torch.zeros(self.buckets, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.recv_keys2 = [torch.zeros(self.cap, dtype=torch.int16, device=self.dev) for _ in range(2)]
+        self.recv_counts2 = [torch.zeros(world * self.mine, dtype=torch.int32, device=self.dev) for _ in range(2)]
         self.recv_flags = torch.zeros(self.cap, dtype=torch.uint8, device=self.dev)
         self.back_flags = torch.zeros(npos, dtype=torch.uint8, device=self.dev)
         self.high = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
         self.total = torch.zeros(max_reads, dtype=torch.int32, device=self.dev)
         self.home_positions = self.home_total = 0
+        self.which = 0
+
+    def use_buffers(self, which):
+        """Which sender (context and exchange buffers) xb_front / xb_recv_buffers work with from now on; xb_finish takes the
+        sender of the step it finishes as an argument."""
+        self.which = which
 
     def xb_front(self, seq, offsets, n_reads, n_bases):
         """-> (keys to send, owner after owner; per-bucket counts by place; keys per owner)"""
-        totals, home = self.nk.xb_front(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, self.send_keys.data_ptr(), self.send_counts.data_ptr(),
-                                        self.world)
+        w = self.which
+        totals, home = self.senders[w].xb_front(seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases, self.send_keys2[w].data_ptr(),
+                                                self.send_counts2[w].data_ptr(), self.world)
         self.home_positions = home
         self.home_total += home
-        return self.send_keys[: sum(totals)], self.send_counts, totals
+        return self.send_keys2[w][: sum(totals)], self.send_counts2[w], totals
 
     def xb_recv_buffers(self, n):
         if n > self.cap:
             raise RuntimeError("received %d keys, more than the %d this rank was sized for" % (n, self.cap))
-        return self.recv_keys[:n], self.recv_counts
+        return self.recv_keys2[self.which][:n], self.recv_counts2[self.which]
 
     def xb_count(self, recv_keys, recv_counts):
         n = recv_keys.numel()
@@ -90,19 +111,24 @@ class HipBucketEngine:
     def xb_back_buffer(self, n):
         return self.back_flags[:n]
 
-    def xb_finish(self, back_flags, offsets, n_reads):
-        self.nk.xb_finish(back_flags.data_ptr(), offsets.data_ptr(), n_reads, self.high.data_ptr(), self.total.data_ptr())
+    def xb_finish(self, back_flags, offsets, n_reads, which):
+        self.senders[which].xb_finish(back_flags.data_ptr(), offsets.data_ptr(), n_reads, self.high.data_ptr(), self.total.data_ptr())
         return self.high[:n_reads], self.total[:n_reads]
 
     def sat_collect(self):
+        """k-mers of this rank's buckets that reached depth - 1 since the last call (device tensor of codes; this rank's own
+        senders know them from here on); None if no saturation bitmap is kept.  Waits for the device."""
         if not self.stay_home:
             return None
         n = self.nk.sat_collect(self.sat_codes.data_ptr(), self.sat_codes.numel())
-        return self.sat_codes[:n]
+        new = self.sat_codes[:n]
+        self.sat_apply(new)
+        return new
 
     def sat_apply(self, codes):
         if self.stay_home and codes.numel():
-            self.nk.sat_apply(codes.data_ptr(), codes.numel())
+            for nk in self.senders:
+                nk.sat_apply(codes.data_ptr(), codes.numel())
 
     def decide(self, high, total, n_units, paired, keep):
         self.nk.decide_device(high.data_ptr(), total.data_ptr(), n_units, paired, keep.data_ptr())
@@ -111,11 +137,22 @@ class HipBucketEngine:
         self.nk.synchronize()
 
     def reset(self):
-        self.nk.reset()
+        for nk in self.senders + [self.nk]:
+            nk.reset()
         self.home_positions = self.home_total = 0
 
     def stats(self):
-        return self.nk.stats()
+        """the owner's table statistics; occurrences the senders answered themselves count as counted and saturated"""
+        st = self.nk.stats()
+        for nk in self.senders:
+            own = nk.stats()
+            st["kmers_counted"] += own["kmers_counted"]
+            st["kmers_saturated"] += own["kmers_saturated"]
+        return st
+
+    def close(self):
+        for nk in self.senders + [self.nk]:
+            nk.close()
 
 
 class BucketedNormaliser(ShardedNormaliser):
@@ -125,12 +162,15 @@ class BucketedNormaliser(ShardedNormaliser):
         super().__init__(engine, group=group, gather_to_root=gather_to_root, stage_through_host=stage_through_host,
                          max_message_bytes=max_message_bytes, check_elems=check_elems, time_phases=time_phases)
 
-    def process_step(self, seq, offsets, n_reads, n_bases, then=None):
-        """seq/offsets: this rank's reads.  Returns (high, total) of this rank's reads, and on rank 0 additionally the
-        gathered (high_all, total_all) per rank.  `then` (the next step's batch, as in ShardedNormaliser) is accepted and
-        not used: nothing of a step starts before the one before it has come home."""
+    def _start_step(self, seq, offsets, n_reads, n_bases):
+        """Everything of a step that does not need the table: partition, compaction, sizes, the exchange of counts and keys
+        (left in flight)."""
         eng, W, me, ph = self.eng, self.world, self.rank, self.phases
         B = eng.buckets
+        self._buffer ^= 1
+        if hasattr(eng, "use_buffers"):
+            eng.use_buffers(self._buffer)
+        x = {"key": (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases), "which": self._buffer}
         err = None
         try:
             with ph.dev("partition + pack"):
@@ -139,30 +179,51 @@ class BucketedNormaliser(ShardedNormaliser):
             err, send_keys, send_counts, totals = e, None, None, [0] * W
         with ph.host("sizes (host round trip)"):
             recv_totals, peak, stop, too_many = self._exchange_counts(totals, seq, err is not None, getattr(eng, "cap", None), n_reads)
-        n_reads_all = self._n_reads_all
+        x["n_reads_all"] = self._n_reads_all
         if stop:
             if err is not None:
                 raise err
             if too_many:
                 raise RuntimeError("received %d keys, more than the %d this rank was sized for" % (sum(recv_totals), eng.cap))
             raise RuntimeError("another rank stopped this step (a read with a byte outside ACGTN, or more keys than it was sized for)")
+        x["totals"], x["recv_totals"], x["peak"] = totals, recv_totals, peak
         n_recv = sum(recv_totals)
         if W == 1:
-            recv_keys, recv_counts = send_keys, send_counts
+            x["recv_keys"], x["recv_counts"], x["owed"] = send_keys, send_counts, []
         else:
-            recv_keys, recv_counts = eng.xb_recv_buffers(n_recv)
+            x["recv_keys"], x["recv_counts"] = eng.xb_recv_buffers(n_recv)
             mine = [first_place(B, W, r + 1) - first_place(B, W, r) for r in range(W)]
-            with ph.dev("key exchange"):
-                # per-bucket counts: to owner r its buckets' part (by place); from every rank one count per bucket of mine
-                self._all_to_all(recv_counts, send_counts, [mine[me]] * W, mine, max(mine))
-                # keys as bytes (two per key): every backend moves uint8
-                self._all_to_all(_as_bytes(recv_keys), _as_bytes(send_keys), [2 * t for t in recv_totals], [2 * t for t in totals], 2 * peak)
+            # per-bucket counts: to owner r its buckets' part (by place); from every rank one count per bucket of mine
+            x["owed"] = self._all_to_all_start(x["recv_counts"], send_counts, [mine[me]] * W, mine, max(mine))
+            # keys as bytes (two per key): every backend moves uint8
+            x["owed"] += self._all_to_all_start(_as_bytes(x["recv_keys"]), _as_bytes(send_keys), [2 * t for t in recv_totals], [2 * t for t in totals], 2 * peak)
             ph.add_bytes("keys sent to other ranks", 2 * (sum(totals) - totals[me]) + 4 * (B - mine[me]))
             ph.add_bytes("keys received from other ranks", 2 * (n_recv - recv_totals[me]) + 4 * mine[me] * (W - 1))
+        x["alive"] = (send_keys, send_counts, seq, offsets)
+        return x
+
+    def process_step(self, seq, offsets, n_reads, n_bases, then=None):
+        """seq/offsets: this rank's reads.  Returns (high, total) of this rank's reads, and on rank 0 additionally the
+        gathered (high_all, total_all) per rank.  then = (seq, offsets, n_reads, n_bases) of the step that follows, if the
+        caller has it already: its k-mers are partitioned and sent while this step's are counted (engines with two senders).
+        All ranks must pass `then` in the same steps, and the next call must be for exactly that batch."""
+        eng, W, me, ph = self.eng, self.world, self.rank, self.phases
+        key = (seq.data_ptr(), offsets.data_ptr(), n_reads, n_bases)
+        x, self._ahead = self._ahead, None
+        if x is not None and x["key"] != key:
+            raise RuntimeError("process_step was announced another batch by the previous call's `then`")
+        if x is None:
+            x = self._start_step(seq, offsets, n_reads, n_bases)
+        with ph.dev("key exchange (not hidden)"):
+            self._all_to_all_finish(x["owed"])
+        if then is not None and hasattr(eng, "use_buffers"):
+            self._ahead = self._start_step(*then)
+        totals, recv_totals = x["totals"], x["recv_totals"]
+        n_recv = sum(recv_totals)
         err = None
         try:
             with ph.dev("count"):
-                recv_flags = eng.xb_count(recv_keys, recv_counts)
+                recv_flags = eng.xb_count(x["recv_keys"], x["recv_counts"])
         except Exception as e:
             err = e
         with ph.host("agree (host round trip)"):
@@ -172,13 +233,13 @@ class BucketedNormaliser(ShardedNormaliser):
         else:
             back = eng.xb_back_buffer(sum(totals))
             with ph.dev("flag exchange"):
-                self._all_to_all(back, recv_flags, totals, recv_totals, peak)
+                self._all_to_all(back, recv_flags, totals, recv_totals, x["peak"])
             ph.add_bytes("flags sent to other ranks", n_recv - recv_totals[me])
         with ph.dev("flags home + per-read sums"):
-            high, total = eng.xb_finish(back, offsets, n_reads)
+            high, total = eng.xb_finish(back, offsets, n_reads, x["which"])
         gathered = None
         if self.gather_to_root:
             with ph.dev("gather to rank 0"):
-                gathered = self._p2p_gather(torch.stack([high, total]), n_reads_all)
+                gathered = self._p2p_gather(torch.stack([high, total]), x["n_reads_all"])
         ph.step_done()
         return high, total, gathered

@@ -29,8 +29,12 @@ class BucketChecker:
         self.mine = self.first[rank + 1] - self.first[rank]
         self.stay_home = stay_home
         self.sat, self.seen, self.home_total = set(), set(), 0
+        self.which, self._fronts = 0, [None, None]
         if not stay_home:
             self.sat_collect = None
+
+    def use_buffers(self, which):
+        self.which = which
 
     def xb_front(self, seq, offsets, n_reads, n_bases):
         codes = Oracle.keys(self.k, self.canonical, seq.numpy(), offsets.numpy().astype(np.uint64))
@@ -40,7 +44,7 @@ class BucketChecker:
         self.home_total += len(home)
         bucket = (codes[pos] >> np.uint64(LOW)).astype(np.int64)
         order = np.argsort(bucket, kind="stable")            # bucket after bucket, stream order within a bucket
-        self._front = (pos[order], home, len(codes))
+        self._fronts[self.which] = (pos[order], home, len(codes))
         counts = np.bincount(bucket, minlength=self.buckets).astype(np.int32)
         totals = [int(counts[self.first[r]:self.first[r + 1]].sum()) for r in range(self.world)]
         low = (codes[pos][order] & np.uint64((1 << LOW) - 1)).astype(np.int16)
@@ -67,8 +71,8 @@ class BucketChecker:
     def xb_back_buffer(self, n):
         return torch.empty(n, dtype=torch.uint8)
 
-    def xb_finish(self, back_flags, offsets, n_reads):
-        pos, home, n = self._front
+    def xb_finish(self, back_flags, offsets, n_reads, which):
+        pos, home, n = self._fronts[which]
         f = np.zeros(n, dtype=np.uint8)
         f[home] = 1
         f[pos] = back_flags.numpy()
@@ -93,19 +97,22 @@ class BucketChecker:
         return {"unique_kmers": self.o.unique}
 
 
-def worker(rank, world, port, k, depth, canonical, steps, q, msg, stay_home, empty_rank):
+def worker(rank, world, port, k, depth, canonical, steps, q, msg, stay_home, empty_rank, ahead=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from nomalise_kmers_multi_large_amd.bucketed import BucketedNormaliser
         sn = BucketedNormaliser(BucketChecker(k, depth, canonical, world, rank, stay_home), max_message_bytes=msg)
-        out = []
+        out, batches = [], []
         for step in range(steps):
             n = 0 if (rank == empty_rank and step == 1) else 40 + 7 * rank   # ragged; one rank brings nothing to one step
             reads = make_reads(100 * step + rank, n, k, 90)
             seq, off = concat(reads) if reads else (np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64))
-            high, total, gathered = sn.process_step(torch.from_numpy(seq), torch.from_numpy(off), len(reads), len(seq))
+            batches.append((torch.from_numpy(seq), torch.from_numpy(off), len(reads), len(seq)))
+        for step in range(steps):
+            # with look-ahead the next step is partitioned and its keys are sent before this step's are counted
+            high, total, gathered = sn.process_step(*batches[step], then=batches[step + 1] if ahead and step + 1 < steps else None)
             if rank == 0:
                 out.append([g.numpy().copy() for g in gathered])
         tallies = torch.tensor([sn.stats()["unique_kmers"], sn.eng.home_total], dtype=torch.int64)
@@ -116,15 +123,16 @@ def worker(rank, world, port, k, depth, canonical, steps, q, msg, stay_home, emp
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,depth,canonical,msg,stay_home,empty_rank", [
-    (2, 7, 3, False, 256 << 20, True, None), (3, 7, 4, True, 256 << 20, True, 1), (2, 9, 2, True, 1000, True, None),
-    (3, 9, 5, False, 256 << 20, False, None), (2, 11, 3, True, 1000, False, 0)])
-def test_bucketed_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg, stay_home, empty_rank):
+@pytest.mark.parametrize("world,k,depth,canonical,msg,stay_home,empty_rank,ahead", [
+    (2, 7, 3, False, 256 << 20, True, None, False), (3, 7, 4, True, 256 << 20, True, 1, False), (2, 9, 2, True, 1000, True, None, False),
+    (3, 9, 5, False, 256 << 20, False, None, False), (2, 11, 3, True, 1000, False, 0, False),
+    (3, 7, 3, True, 256 << 20, True, 1, True), (2, 9, 2, False, 1000, True, 0, True)])
+def test_bucketed_exchange_equals_single_stream(oracle_lib, world, k, depth, canonical, msg, stay_home, empty_rank, ahead):
     steps = 4
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg, stay_home, empty_rank)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, k, depth, canonical, steps, q, msg, stay_home, empty_rank, ahead)) for r in range(world)]
     for p in procs:
         p.start()
     got, (uniq, stayed) = q.get(timeout=120)

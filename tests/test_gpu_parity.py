@@ -646,13 +646,16 @@ def _bucket_rank_worker(rank, world, port, steps, bp, k, depth, stay_home, q):
     try:
         eng = HipBucketEngine(k, depth, 0.9, False, 0, 2 * bp, 2 * bp * 150, world, rank, slack=2.0, stay_home=stay_home)
         sn = BucketedNormaliser(eng, stage_through_host=True, max_message_bytes=1 << 20)
-        out = []
+        out, batches = [], []
         for step, (c1, c2) in enumerate(synth.pair_blocks(steps * bp, seed=11 + rank, transcripts=30, block=bp)):
             if rank == world - 1 and step == 1:   # the last rank brings nothing to the second step
                 seq, off = np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64)
             else:
                 seq, off = synth.interleave(c1, c2)
-            high, total, gathered = sn.process_step(torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq))
+            batches.append((torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda(), len(off) - 1, len(seq)))
+        for step, batch in enumerate(batches):
+            # the first step announces the second: that one is partitioned and its k-mers travel before the first is counted
+            high, total, gathered = sn.process_step(*batch, then=batches[1] if step == 0 else None)
             sn.synchronize()
             if rank == 0:
                 out.append([g.cpu().numpy().copy() for g in gathered])
