@@ -3364,12 +3364,14 @@ int nkml_sat_collect(nkml_ctx *c, uint32_t *d_codes, uint64_t max_codes, uint64_
         first = xb_first(c->xb_buckets, c->xb_world, c->xb_rank);
         grid = xb_first(c->xb_buckets, c->xb_world, c->xb_rank + 1) - first;
     }
+    const uint32_t n_buckets = grid;
+    if (grid > 1024) grid = 1024; // four workgroups per CU, each with 32 KiB of LDS for its new k-mers, buckets in turns
     if (c->pt_wide)
-        hipLaunchKernelGGL((k_sat_collect<uint16_t>), grid, 256, 0, c->stream, (const uint16_t *)c->pt_table, c->xb_order, first, (uint32_t)c->cfg.depth, c->sat_bits,
-                           d_codes, (uint32_t)max_codes, c->d_ctr);
+        hipLaunchKernelGGL((k_sat_collect<uint16_t>), grid, 256, 0, c->stream, (const uint16_t *)c->pt_table, c->xb_order, first, n_buckets, (uint32_t)c->cfg.depth,
+                           c->sat_bits, d_codes, (uint32_t)max_codes, c->d_ctr);
     else
-        hipLaunchKernelGGL((k_sat_collect<uint8_t>), grid, 256, 0, c->stream, (const uint8_t *)c->pt_table, c->xb_order, first, (uint32_t)c->cfg.depth, c->sat_bits,
-                           d_codes, (uint32_t)max_codes, c->d_ctr);
+        hipLaunchKernelGGL((k_sat_collect<uint8_t>), grid, 256, 0, c->stream, (const uint8_t *)c->pt_table, c->xb_order, first, n_buckets, (uint32_t)c->cfg.depth,
+                           c->sat_bits, d_codes, (uint32_t)max_codes, c->d_ctr);
     HIPCHK(c, hipGetLastError());
     if (int rc = fetch_counters(c)) return rc;
     // More than the list holds: the bits are set here, the list only feeds other ranks' bitmaps, which may lag for good -
@@ -3506,8 +3508,10 @@ int nkml_xb_count(nkml_ctx *c, const uint16_t *d_recv_keys, const uint32_t *d_re
     hipLaunchKernelGGL(k_xb_merge<true>, mine * W, 64, 0, c->stream, d_recv_keys, (uint8_t *)nullptr, d_recv_counts, c->xb_run_at, W, mine, c->xb_order, first, c->xb_bounds2,
                        c->xb_keys2, (const uint8_t *)nullptr);
     HIPCHK(c, hipGetLastError());
+    c->broken = true; // from here on part of the step is in the table: a failure leaves the context unusable until nkml_reset
     int rc = pt_count_buckets(c, c->xb_keys2, c->xb_bounds2, c->xb_flags2, false, false);
     if (rc != NKML_OK) return rc;
+    c->broken = false;
     hipLaunchKernelGGL(k_xb_merge<false>, mine * W, 64, 0, c->stream, (const uint16_t *)nullptr, d_recv_flags, d_recv_counts, c->xb_run_at, W, mine, c->xb_order, first,
                        c->xb_bounds2, (uint16_t *)nullptr, c->xb_flags2);
     HIPCHK(c, hipGetLastError());
