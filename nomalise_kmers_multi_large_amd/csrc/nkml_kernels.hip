@@ -2093,7 +2093,7 @@ int verify_snapshot(nkml_ctx *c, const void *table, uint64_t bytes)
 }
 
 // ... and after the batch's last kernel: wait, read the tally, fail the batch if anything was out of place
-int verify_verdict(nkml_ctx *c)
+int verify_outcome(nkml_ctx *c)
 {
     int rc = fetch_counters(c);
     if (rc != NKML_OK) return rc;
@@ -2260,7 +2260,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
         c->pt_timed_keys = n;
         c->pt_timing_pending = true;
     }
-    if (verify) return verify_verdict(c);
+    if (verify) return verify_outcome(c);
     return NKML_OK;
 }
 
@@ -2533,7 +2533,7 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
         c->pt_timed_keys = n;
         c->pt_timing_pending = true;
     }
-    if (verify) return verify_verdict(c);
+    if (verify) return verify_outcome(c);
     return NKML_OK;
 }
 
