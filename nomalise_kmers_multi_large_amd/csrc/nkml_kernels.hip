@@ -3465,6 +3465,14 @@ int nkml_xb_front(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, 
     HIPCHK(c, hipMemsetAsync(c->pt_histA + 256 * ta, 0, 256 * sizeof(pt_hist_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->pt_histB + 256 * tb, 0, 256 * sizeof(pt_hist_t), c->stream));
     if ((rc = pt_forward(c, nullptr, n, n_bases, false)) != NKML_OK) return rc;
+    if (c->verify) { // NKML_F_VERIFY_RANKS: both passes against a stable partition built without the LDS's lane order
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->verify_bad, 0, sizeof(unsigned int), c->stream));
+        VerifySource sa{nullptr, n, nullptr, c->d_packed, c->d_startbits, n_bases, n / 16, c->cfg.ksize, 0, 1, 0};
+        verify_pass<uint32_t, uint32_t>(c, sa, (uint32_t)ta, PT_LOWBITS, c->pt_scanA, c->pt_keysA, 0xffffffffull);
+        VerifySource sb{c->pt_keysA, 0, c->pt_pad + 256, nullptr, nullptr, 0, 0, c->cfg.ksize, 0, 1, 0};
+        verify_pass<uint32_t, uint16_t>(c, sb, (uint32_t)tb, PT_LOWBITS + 8, c->pt_scanB, c->pt_keysB, (1ull << PT_LOWBITS) - 1);
+        HIPCHK(c, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_pt_bucket_bounds, B / 256 + 1, 256, 0, c->stream, c->pt_scanB, c->pt_pad, B, c->pt_bounds);
     HIPCHK(c, hipMemsetAsync(c->xb_kept + B, 0, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_xb_mark, B, 64, 0, c->stream, c->pt_keysB, c->pt_bounds, c->sat_bits, c->xb_place, c->xb_kept);
@@ -3485,6 +3493,8 @@ int nkml_xb_front(nkml_ctx *c, const uint8_t *d_seq, const uint64_t *d_offsets, 
     c->route_home_total += home;
     if (n_home) *n_home = home;
     c->xb_n = n;
+    if (c->verify && c->h_ctr->verify_bad) // (the counters were fetched above, after the checks had run)
+        return fail(c, NKML_E_STATE, "rank verification: %u elements of the batch are not where a stable partition puts them", c->h_ctr->verify_bad);
     return check_bad_bases(c);
 }
 
@@ -3508,10 +3518,25 @@ int nkml_xb_count(nkml_ctx *c, const uint16_t *d_recv_keys, const uint32_t *d_re
     hipLaunchKernelGGL(k_xb_merge<true>, mine * W, 64, 0, c->stream, d_recv_keys, (uint8_t *)nullptr, d_recv_counts, c->xb_run_at, W, mine, c->xb_order, first, c->xb_bounds2,
                        c->xb_keys2, (const uint8_t *)nullptr);
     HIPCHK(c, hipGetLastError());
+    int rc;
+    if (c->verify) { // NKML_F_VERIFY_RANKS: the bucket kernels' work against a copy of the table from before the step
+        const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
+        if ((rc = verify_snapshot(c, c->pt_table, entries * (c->pt_wide ? 2 : 1))) != NKML_OK) return rc;
+    }
     c->broken = true; // from here on part of the step is in the table: a failure leaves the context unusable until nkml_reset
-    int rc = pt_count_buckets(c, c->xb_keys2, c->xb_bounds2, c->xb_flags2, false, false);
-    if (rc != NKML_OK) return rc;
+    if ((rc = pt_count_buckets(c, c->xb_keys2, c->xb_bounds2, c->xb_flags2, false, false)) != NKML_OK) return rc;
     c->broken = false;
+    if (c->verify) {
+        const size_t vf_lds = 3 * VF_WINDOW * sizeof(uint32_t);
+        if (c->pt_wide)
+            hipLaunchKernelGGL((k_verify_bucket<uint16_t>), B, 512, vf_lds, c->stream, c->xb_keys2, c->xb_bounds2, (const uint16_t *)c->pt_table,
+                               (const uint16_t *)c->vf_before, (uint32_t)c->cfg.depth, c->xb_flags2, c->d_ctr);
+        else
+            hipLaunchKernelGGL((k_verify_bucket<uint8_t>), B, 512, vf_lds, c->stream, c->xb_keys2, c->xb_bounds2, (const uint8_t *)c->pt_table,
+                               (const uint8_t *)c->vf_before, (uint32_t)c->cfg.depth, c->xb_flags2, c->d_ctr);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = verify_outcome(c)) != NKML_OK) return rc;
+    }
     hipLaunchKernelGGL(k_xb_merge<false>, mine * W, 64, 0, c->stream, (const uint16_t *)nullptr, d_recv_flags, d_recv_counts, c->xb_run_at, W, mine, c->xb_order, first,
                        c->xb_bounds2, (uint16_t *)nullptr, c->xb_flags2);
     HIPCHK(c, hipGetLastError());
