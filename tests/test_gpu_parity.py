@@ -1212,6 +1212,59 @@ for k in (15, 25):
     assert "PASSED" not in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,canonical", [(15, False), (25, True)])
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8, 32])
+def test_ranked_routing_sends_every_kmer_to_its_place(nk, k, canonical, n_shards):
+    """nkml_route_reads_ranked on its own: with the 16 bits it leaves per base position and the tiles' start offsets, the key
+    of every position is found at offsets[shard][tile] + rank in what is sent, shard = nkml_owner_of(key); positions
+    without a k-mer say so; every shard's segment is in stream order (places grow with the position); and
+    nkml_unroute_ranked brings a flag per sent key back to exactly the position it came from."""
+    import torch
+    rng = np.random.default_rng(50 + k + n_shards)
+    reads = random_reads(rng, 400, k, 200, b"ACGT", 0.02) + random_reads(rng, 200, k, 4 * k, b"AC") + [b"A" * 60, b"N" * 45, b"G" * 150] * 5
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    with nk.KmerNormaliser(k, 10, 0.9, canonical, device=0, max_batch_reads=4096, max_batch_bases=1 << 20) as g:
+        seq, off = g._concat(reads)
+        nb, n16 = len(seq), (len(seq) + 15) // 16 * 16
+        d_seq, d_off = torch.from_numpy(seq.copy()).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        wide = g.key_bytes == 8
+        kt = torch.int64 if wide else torch.int32
+        keys = torch.zeros(n16, dtype=kt, device="cuda")
+        g.kmerise_device(d_seq.data_ptr(), d_off.data_ptr(), len(reads), nb, keys.data_ptr())
+        tiles = (n16 + 1023) // 1024
+        send = torch.full((n16,), -1, dtype=kt, device="cuda")
+        meta = torch.zeros(tiles * 1024, dtype=torch.int16, device="cuda")
+        tile_off = torch.zeros(tiles * n_shards + 1, dtype=torch.int32, device="cuda")
+        counts, home = g.route_reads_ranked(d_seq.data_ptr(), d_off.data_ptr(), len(reads), nb, n_shards, send.data_ptr(), meta.data_ptr(), tile_off.data_ptr())
+        g.synchronize()
+        assert home == 0
+        kh = keys.cpu().numpy().astype(np.uint64 if wide else np.uint32).astype(np.uint64)
+        m = meta.cpu().numpy().view(np.uint16)[:n16].astype(np.int64)
+        to = tile_off.cpu().numpy().astype(np.int64)
+        sent = send.cpu().numpy().astype(np.uint64 if wide else np.uint32).astype(np.uint64)
+        has = kh != 0
+        assert sum(counts) == int(has.sum()) and ((m == 0x8000) == ~has).all()
+        pos = np.nonzero(has)[0]
+        own, rank = m[pos] >> 10, m[pos] & 1023
+        want_own = ((((kh[pos] * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)) * np.uint64(n_shards)) >> np.uint64(32)).astype(np.int64)
+        np.testing.assert_array_equal(own, want_own)
+        place = to[own * tiles + (pos >> 10)] + rank
+        np.testing.assert_array_equal(sent[place], kh[pos])
+        assert len(np.unique(place)) == len(place) and place.max() == sum(counts) - 1
+        for s in range(n_shards):   # stream order inside every shard's segment, segments back to back in shard order
+            ps = place[own == s]
+            assert (np.diff(ps) > 0).all() and (len(ps) == 0 or (ps[0] == sum(counts[:s]) and ps[-1] == sum(counts[:s + 1]) - 1))
+        # the way home: a flag per sent key (here: its place modulo 251 + 1) arrives at the position the key came from
+        back = torch.from_numpy(((np.arange(sum(counts)) % 251) + 1).astype(np.uint8)).cuda()
+        flags = torch.full((n16,), 77, dtype=torch.uint8, device="cuda")
+        g.unroute_ranked(back.data_ptr(), meta.data_ptr(), tile_off.data_ptr(), n16, flags.data_ptr())
+        g.synchronize()
+        f = flags.cpu().numpy()
+        np.testing.assert_array_equal(f[pos], (place % 251) + 1)
+        assert (f[~has] == 0).all()
+
+
 # ---- routing on its own: the whole output against a stable partition computed with numpy ----
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [15, 25])
