@@ -2413,7 +2413,12 @@ int run_count_hashpart(nkml_ctx *c, const unsigned long long *d_keys, uint64_t n
     // table through LDS, so a table larger than needed costs bandwidth; one that turns out too small costs a relaunch.
     {
         const uint64_t now = c->h_ctr->unique, added = now > c->hp_unique_before ? now - c->hp_unique_before : 0;
-        while ((double)(now + added) >= 0.75 * (double)c->capacity && c->hp_log2_bucket < HP_MAX_LOG2_BUCKET) {
+        static const double grow_load = [] { // tuning aid: NKML_HP_GROW_LOAD=0.5 .. 0.95
+            const char *e = getenv("NKML_HP_GROW_LOAD");
+            const double v = e ? atof(e) : 0.0;
+            return v >= 0.5 && v <= 0.95 ? v : 0.75;
+        }();
+        while ((double)(now + added) >= grow_load * (double)c->capacity && c->hp_log2_bucket < HP_MAX_LOG2_BUCKET) {
             if (hp_grow(c, false) != NKML_OK) break; // no room for a larger table now: the bucket kernel will say if it is needed
         }
         c->hp_unique_before = now;
