@@ -74,7 +74,7 @@ typedef struct nkml_config {
                                   the top 16 bits of a hash of the code against a table of 8-byte slots that is swept once
                                   per batch and doubles when a bucket fills up.  With neither flag the library chooses:
                                   partitioned at k = 15 and, for batches up to about 2 M pairs of 150 bases, at k = 14;
-                                  partitioned at k > 16 while the table has at most 3 slots per position of a full batch,
+                                  partitioned at k > 16 while the table has at most 4 slots per position of a full batch,
                                   atomics from then on (the stored k-mers move over, between two batches, for good: the
                                   sweep of a large table costs more than the random accesses it replaces - nkml_stats
                                   .partitioned tells which path a context is on); atomics otherwise.  The environment

@@ -2329,7 +2329,7 @@ int hp_grow(nkml_ctx *c, bool batch_under_way)
 
 // The partitioned path sweeps the whole table through LDS once per batch, the atomic path touches one slot per k-mer
 // occurrence: once the table has grown well beyond a batch's positions, the sweep costs more than the random accesses it
-// replaced (measured on 150-base pairs: 2 M-pair batches break even between 2^30 and 2^31 slots, 0.7 M-pair batches near 2^29).  From
+// replaced (measured on 150-base pairs: 2 M-pair batches break even between 2^31 and 2^32 slots, 0.7 M-pair batches between 2^29 and 2^30).  From
 // then on the context counts on the atomic path: every stored k-mer moves to a table of 16-byte slots (same number of
 // slots; count as it stands; saturated if count >= depth - 1, which is what both paths hold between batches), the
 // partition buffers go, the atomic path's lists come.  Called between batches only.  If the memory for the move is not
@@ -2699,11 +2699,11 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
     c->posbits = 0;
     while ((1ull << c->posbits) < npos) c->posbits++;
     if (c->hashpart) {
-        // chosen by default: stay while the table has at most 3 slots per position of a full batch (hp_leave);
+        // chosen by default: stay while the table has at most 4 slots per position of a full batch (hp_leave);
         // asked for by flag or environment: stay for good
         const char *env = getenv("NKML_PARTITIONED");
         const bool forced = (cfg->flags & NKML_F_COUNT_PARTITIONED) || (env && env[0] == '1');
-        c->hp_leave_slots = forced ? 0 : 3 * npos;
+        c->hp_leave_slots = forced ? 0 : 4 * npos;
         if (const char *e = getenv("NKML_HP_LEAVE_SLOTS")) c->hp_leave_slots = strtoull(e, nullptr, 10); // test aid
     }
 
