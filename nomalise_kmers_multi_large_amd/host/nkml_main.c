@@ -421,6 +421,10 @@ struct plan {
     size_t t_units[MAX_THREADS], t_bases[MAX_THREADS], t_bad[MAX_THREADS];
     size_t t_seedable[2][MAX_THREADS], t_unused[MAX_THREADS]; /* records whose fwd / rev read is longer than k; records not counted */
     int t_bad_rev[MAX_THREADS], long_line;
+    /* where the alphabet is checked: in the sizing pass (seeding pass: it has to know before it stages anything), or in the
+     * staging pass on the bytes just copied (record loop: one pass over the sequence lines instead of two) */
+    bool size_validates;
+    size_t t_bad_unit[MAX_THREADS]; /* staging pass: units staged before the thread's first bad record */
     /* formatting pass, per thread; two sets of buffers take turns, so that one window's kept records can still be on
      * their way to the files while the next window's are formatted */
     int set;
@@ -539,8 +543,10 @@ static void size_records(int tid, int nt, void *arg)
         seedable_r += P.paired && lr > P.K;
         if (!long_enough) { unused++; continue; } /* dropped without being counted anywhere, ref:1630-1631 */
         if (lf > MAX_LINE || lr > MAX_LINE) continue; /* reported after the phase */
-        if (!valid_bases(sf, lf)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 0; break; }
-        if (P.paired && !valid_bases(sr, lr)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 1; break; }
+        if (P.size_validates) {
+            if (!valid_bases(sf, lf)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 0; break; }
+            if (P.paired && !valid_bases(sr, lr)) { P.t_bad[tid] = i; P.t_bad_rev[tid] = 1; break; }
+        }
         units++;
         bases += (size_t)lf + lr;
     }
@@ -551,7 +557,9 @@ static void size_records(int tid, int nt, void *arg)
     P.t_unused[tid] = unused;
 }
 
-/* Phase 2: sequence lines into the staging area, in record order */
+/* Phase 2: sequence lines into the staging area, in record order; unless the sizing pass has done it, the alphabet check
+ * of is_valid_sequence_pair / _single (ref:1404-1457) on the bytes just copied.  A thread stops at its first record with a
+ * bad base (the reference exits there; what other threads stage beyond it is never submitted). */
 static void stage_records(int tid, int nt, void *arg)
 {
     (void)arg;
@@ -560,6 +568,8 @@ static void stage_records(int tid, int nt, void *arg)
     size_t u = 0, at = 0;
     for (int t = 0; t < tid; t++) { u += P.t_units[t]; at += P.t_bases[t]; }
     const size_t u_end = u + P.t_units[tid];
+    const bool validate = !P.size_validates;
+    if (validate) P.t_bad[tid] = SIZE_MAX;
     for (size_t i = a; i < b && u < u_end; i++) {
         if (!W->use[i]) continue;
         uint32_t lf, lr = 0;
@@ -574,6 +584,11 @@ static void stage_records(int tid, int nt, void *arg)
         } else {
             memcpy(B.seq + at, sf, lf);
             B.offsets[u + 1] = at + lf;
+        }
+        if (validate) {
+            const char *copy = (const char *)B.seq + at;
+            const int bad_read = !valid_bases(copy, lf) ? 0 : (P.paired && !valid_bases(copy + lf, lr)) ? 1 : -1;
+            if (bad_read >= 0) { P.t_bad[tid] = i; P.t_bad_rev[tid] = bad_read; P.t_bad_unit[tid] = u; break; }
         }
         at += (size_t)lf + lr;
         u++;
@@ -950,6 +965,7 @@ static void process_files(const struct mapped *fwd, const struct mapped *rev)
     P.paired = rev != NULL;
     P.to_fasta = cfg.fastq_in && !cfg.fastq_out;
     P.K = (uint32_t)cfg.ksize;
+    P.size_validates = false;
     size_t pos_f = 0, pos_r = 0;
     size_t bytes_per_rec = 512; /* window size guess; follows the data */
     struct window *prev = NULL;
@@ -968,6 +984,17 @@ static void process_files(const struct mapped *fwd, const struct mapped *rev)
                 TIMED(6, lazy_seed_window());
             }
             TIMED(2, parallel_run(stage_records, NULL));
+            /* a record with a bad base: the window ends before it (everything before it is counted and written, see below) */
+            for (int t = 0; t < n_threads; t++)
+                if (P.t_bad[t] < bad) {
+                    bad = P.t_bad[t];
+                    bad_rev = P.t_bad_rev[t];
+                    W->n_units = (uint32_t)P.t_bad_unit[t];
+                }
+            if (bad != SIZE_MAX) {
+                W->n_reads = P.paired ? 2 * W->n_units : W->n_units;
+                W->n_bases = B.offsets[W->n_reads];
+            }
         }
         if (prev && !prev_done) { W = prev; finish_window(); W = cur; }
         if (more) submit_window();
@@ -1013,6 +1040,7 @@ static void seed_file(const char *name, int limit)
     P.lines = cfg.fastq_in ? 4 : 2;
     P.paired = false;
     P.K = (uint32_t)cfg.ksize + 1; /* strictly longer than k, ref:1352 */
+    P.size_validates = true;
     size_t size = m.size;
     /* the reference only sees complete, newline-terminated lines: stop at the last newline */
     while (size > 0 && m.data[size - 1] != '\n') size--;
