@@ -90,6 +90,9 @@ typedef struct nkml_config {
                                   Several times slower, one table copy more in memory: for validation runs on new hardware,
                                   drivers or compilers.  The environment variable NKML_VERIFY_RANKS=1 sets it as well.
                                   No effect on the atomic path (its ranks come from a sort). */
+#define NKML_F_NO_TABLE 32u     /* no table: the context only plays the sender of the bucket-ordered exchange (nkml_xb_front /
+                                  nkml_xb_finish, nkml_sat_apply) - k <= 15 with NKML_F_COUNT_PARTITIONED; every call that
+                                  would count returns NKML_E_STATE.  Saves the 4^k-entry table and its clearing. */
 
 typedef struct nkml_stats {
     uint64_t unique_kmers;     /* hash_table->used (ref:166, 965): distinct non-zero codes stored, seeded ones included */

@@ -15,6 +15,7 @@ NKML_F_EXACT_COUNTS = 2
 NKML_F_COUNT_ATOMIC = 4
 NKML_F_COUNT_PARTITIONED = 8
 NKML_F_VERIFY_RANKS = 16
+NKML_F_NO_TABLE = 32
 FLAG_NONE, FLAG_HIGH, FLAG_LOW = 0, 1, 2
 
 # every symbol include/nkml_hip.h declares

@@ -35,8 +35,8 @@ class HipBucketEngine:
     """Stage-by-stage face of the HIP library's bucket-ordered exchange on one GPU, holding torch tensors for the buffers.
     Three library contexts: two that play the sender (pack, partition, compact; the way home) for alternate steps, so that a
     step's k-mers can be partitioned and sent while the step before it is still being counted and brought home, and one that
-    owns this rank's buckets of the table.  (A sender never touches its context's table, the owner never its partition
-    buffers, which are created small.)"""
+    owns this rank's buckets of the table.  (The senders are created without a table, the owner with partition buffers for
+    next to nothing.)"""
 
     MAX_NEW_SATURATED = 1 << 23
 
@@ -53,7 +53,7 @@ class HipBucketEngine:
         self.senders = []
         for _ in range(2):
             nk = KmerNormaliser(ksize, depth, coverage, canonical, device=device, max_batch_reads=max_reads, max_batch_bases=max_bases,
-                                flags=B.NKML_F_COUNT_PARTITIONED)
+                                flags=B.NKML_F_COUNT_PARTITIONED | B.NKML_F_NO_TABLE)
             nk.set_stream(stream)
             nk.xb_enable(world, rank, 16)
             self.senders.append(nk)

@@ -1684,7 +1684,7 @@ int alloc_table(nkml_ctx *c)
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hp_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HB_MAX_SLOTS * 8)));
         } else {
             c->capacity = 1ull << (2 * c->cfg.ksize);
-            HIPCHK(c, hipMalloc(&c->pt_table, pt_table_bytes(c)));
+            if (!(c->cfg.flags & NKML_F_NO_TABLE)) HIPCHK(c, hipMalloc(&c->pt_table, pt_table_bytes(c)));
         }
         c->pt_tiles_a = (npos + PT_TILE - 1) / PT_TILE;
         c->pt_tiles_b = c->pt_tiles_a + 256 + 1;
@@ -1761,7 +1761,7 @@ int clear_table(nkml_ctx *c)
     if (c->hashpart) {
         HIPCHK(c, zero_device(c->hp_table, c->capacity * sizeof(unsigned long long), c->stream));
     } else if (c->partitioned) {
-        HIPCHK(c, zero_device(c->pt_table, pt_table_bytes(c), c->stream));
+        if (c->pt_table) HIPCHK(c, zero_device(c->pt_table, pt_table_bytes(c), c->stream));
     } else if (c->direct) {
         uint64_t bm = c->capacity / 8 < 256 ? 256 : c->capacity / 8;
         HIPCHK(c, zero_device(c->counts, c->capacity * sizeof(uint32_t), c->stream));
@@ -2209,6 +2209,7 @@ int run_count_partitioned(nkml_ctx *c, const void *d_keys_any, uint64_t n, uint6
     if (n == 0) return NKML_OK;
     if (c->hashpart) return run_count_hashpart(c, static_cast<const unsigned long long *>(d_keys_any), n, n_bases, d_flags, seeding);
     const uint32_t *d_keys = static_cast<const uint32_t *>(d_keys_any);
+    if (!c->pt_table) return fail(c, NKML_E_STATE, "the context was created without a table (NKML_F_NO_TABLE)");
     if (n > c->max_words * 16) return fail(c, NKML_E_ARG, "%llu keys exceed the context's batch size", (unsigned long long)n);
     const bool profile = (c->cfg.flags & NKML_F_PROFILE) != 0 && !seeding;
     int rc;
@@ -2681,6 +2682,10 @@ int nkml_create(const nkml_config *cfg, nkml_ctx **out)
         if (cfg->flags & NKML_F_COUNT_PARTITIONED) want_hp = true;
         if (cfg->flags & NKML_F_COUNT_ATOMIC) want_hp = false;
         if (can_hp && want_hp) c->partitioned = c->hashpart = true;
+        if ((cfg->flags & NKML_F_NO_TABLE) && (!c->partitioned || c->hashpart)) {
+            delete c;
+            return NKML_E_ARG; // a context without a table only makes sense as a sender of the bucket-ordered exchange (k <= 15)
+        }
     }
     {
         const char *env = getenv("NKML_VERIFY_RANKS");
@@ -3360,6 +3365,7 @@ int nkml_sat_collect(nkml_ctx *c, uint32_t *d_codes, uint64_t max_codes, uint64_
 {
     if (!c || !n_codes || (max_codes && !d_codes) || max_codes >= (1ull << 32)) return NKML_E_ARG;
     if (!c->sat_bits) return fail(c, NKML_E_STATE, "nkml_sat_enable first");
+    if (!c->pt_table) return fail(c, NKML_E_STATE, "the context was created without a table (NKML_F_NO_TABLE)");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint64_t entries = c->capacity < (1ull << PT_LOWBITS) ? (1ull << PT_LOWBITS) : c->capacity;
     HIPCHK(c, hipMemsetAsync(&c->d_ctr->sat_new, 0, sizeof(unsigned int), c->stream));
@@ -3507,6 +3513,7 @@ int nkml_xb_count(nkml_ctx *c, const uint16_t *d_recv_keys, const uint32_t *d_re
 {
     if (!c || !d_recv_counts || (n_recv && (!d_recv_keys || !d_recv_flags))) return NKML_E_ARG;
     if (!c->xb_order) return fail(c, NKML_E_STATE, "nkml_xb_enable first");
+    if (!c->pt_table) return fail(c, NKML_E_STATE, "the context was created without a table (NKML_F_NO_TABLE)");
     if (c->broken) return broken_context(c);
     if (n_recv > c->xb_capacity) return fail(c, NKML_E_ARG, "%llu keys arrived, the context was sized for %llu", (unsigned long long)n_recv, (unsigned long long)c->xb_capacity);
     if (n_recv == 0) return NKML_OK;
@@ -3596,6 +3603,7 @@ static int dump_table_into(nkml_ctx *c, unsigned long long *d_codes, uint32_t *d
 int nkml_dump_table(nkml_ctx *c, uint64_t *codes, uint32_t *counts, uint64_t max_entries, uint64_t *n_entries)
 {
     if (!c || !n_entries || (max_entries && (!codes || !counts))) return NKML_E_ARG;
+    if (c->partitioned && !c->hashpart && !c->pt_table) return fail(c, NKML_E_STATE, "the context was created without a table (NKML_F_NO_TABLE)");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     unsigned long long *d_codes = nullptr, *d_n = nullptr;
     uint32_t *d_cnts = nullptr;

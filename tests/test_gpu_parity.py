@@ -1265,6 +1265,24 @@ def test_ranked_routing_sends_every_kmer_to_its_place(nk, k, canonical, n_shards
         assert (f[~has] == 0).all()
 
 
+@pytest.mark.gpu
+def test_a_context_without_a_table_refuses_to_count(nk):
+    """NKML_F_NO_TABLE: the sender-only contexts of the bucket-ordered exchange hold no table; every call that would count says
+    so (NKML_E_STATE) instead of touching memory that is not there, and the flag is refused where it makes no sense (k > 16)."""
+    from nomalise_kmers_multi_large_amd import binding as B
+    flags = B.NKML_F_COUNT_PARTITIONED | B.NKML_F_NO_TABLE
+    with nk.KmerNormaliser(15, 20, 0.9, False, max_batch_reads=64, max_batch_bases=64 * 150, flags=flags) as g:
+        assert g.stats()["partitioned"] == 1
+        with pytest.raises(B.NkmlError) as e:
+            g.process_sequence_single([b"ACGTACGTTGCATGCAAGCTTGCA" * 3])
+        assert e.value.code == B.NKML_E_STATE and "without a table" in str(e.value)
+        with pytest.raises(B.NkmlError) as e:
+            g.dump_table(16)
+        assert e.value.code == B.NKML_E_STATE
+    with pytest.raises(B.NkmlError):
+        nk.KmerNormaliser(25, 20, 0.9, True, max_batch_reads=64, max_batch_bases=64 * 150, flags=flags)
+
+
 # ---- routing on its own: the whole output against a stable partition computed with numpy ----
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", [15, 25])
